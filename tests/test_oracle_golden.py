@@ -1,0 +1,340 @@
+"""Pins the CPU oracle (oracle/nic_oracle.py) against the fixtures produced by running the reference
+itself (oracle/make_golden.py).  Index / encode / codec arithmetic must be bit-exact; the
+floating-point network is held to 1e-6 (different BLAS blocking orders are the only freedom)."""
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nic_oracle as O
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def exact(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a, b), (what, float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    assert np.all(err <= atol + rtol * np.abs(b)), (what, float(err.max()))
+
+
+def digest_close(d, ref, rtol=1e-6, what=""):
+    d, ref = np.asarray(d), np.asarray(ref)
+    assert np.all(np.abs(d - ref) <= rtol * np.maximum(1.0, np.abs(ref))), (what, d, ref)
+
+
+# ---------------------------------------------------------------------------------------- G1
+def test_level_maps(golden):
+    g = golden("levels")
+    for image_size, base in [(512, 128), (64, 16), (1024, 256), (256, 64), (128, 32), (16, 4)]:
+        m = O.create_pyramid_mip_levels(image_size, base)
+        ref = g[f"map_{image_size}_{base}"]
+        assert sorted(m.keys()) == list(ref[:, 0])
+        assert [m[k] for k in ref[:, 0]] == list(ref[:, 1])
+    for s, p, l in zip(g["sizes"], g["two_power"], g["levels"]):
+        assert O.return_2_power(int(s)) == p and O.return_pyramid_levels(int(s)) == l
+    # the values test03.py prints
+    assert O.return_pyramid_levels(128) == 4 and O.return_2_power(1024) == 10
+    assert O.create_pyramid_mip_levels(512, 128) == {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 2, 7: 2, 8: 3, 9: 3}
+
+
+def test_step_guard():
+    # Q6: only step_number == 2 disables the G1 weights
+    for e in range(-3, 4):
+        s = pow(2, e)
+        assert O.g1_weights_enabled(s) == (s != 2)
+
+
+# ---------------------------------------------------------------------------------------- G2 / G3
+def test_positional_encodings(golden):
+    g = golden("pe")
+    exact(O.triangular_positional_encoding(t(g["tri_c1_in"]), 6), g["tri_c1"])
+    # known answers recorded in SURVEY 8c
+    assert np.allclose(g["tri_c1"][0], [1, .9375, .875, .75, .5, .25, 0, -.9375])
+    assert np.allclose(g["tri_c1"][4], [1, .75, .5, 0, -1, 0, 1, .75]) and not g["tri_c1"][5].any()
+    exact(O.triangular_positional_encoding(t(g["tri_test14_in"]).to(torch.float32), 6), g["tri_test14"])
+    for D in (2, 3):
+        c = t(g[f"coords_d{D}"])
+        exact(O.triangular_positional_encoding(c, 6), g[f"tri_d{D}"])
+        exact(O.triangular_positional_encoding(c, 4), g[f"tri_d{D}_p4"])
+        exact(O.positional_encoding(tuple(c[i] for i in range(D)), 6), g[f"sin_d{D}"])
+        exact(O.positional_encoding(tuple(c[i] for i in range(D)), 8), g[f"sin_d{D}_p8"])
+    a = t(g["coords_arb"])
+    exact(O.triangular_positional_encoding(a, 6), g["tri_arb"])
+    exact(O.positional_encoding((a[0], a[1]), 6), g["sin_arb"])
+
+
+def test_lut_positional_encoding(golden):
+    g = golden("pe")
+    lut = O.triangular_lut_1d()
+    exact(lut, g["lut1d_encodings"])
+    exact(lut, g["fn1d"])
+    exact(O.triangular_lut_forward(lut, t(g["lut1d_in"])), g["lut1d_out"])
+    lut2 = O.triangular_lut_1d(16, 4, False)
+    exact(lut2, g["lut1d_16_4_encodings"])
+    exact(O.triangular_lut_forward(lut2, t(g["lut1d_in"])), g["lut1d_16_4_out"])
+    exact(O.triangular_positional_encoding_2d(torch.tensor([[0, 0]]), 8, 8), g["fn2d_00_8_8"])
+    cc = t(g["fn2d_in"])
+    exact(O.triangular_positional_encoding_2d(cc, 4, 4), g["fn2d_4_4"])
+    exact(O.triangular_positional_encoding_2d(cc, 4, 4, stride=2), g["fn2d_4_4_s2"])
+    fx, fy = O.convert_coordinate_start(cc, 4, 4)
+    exact(fx, g["ccs_x"]); exact(fy, g["ccs_y"])
+
+
+# ---------------------------------------------------------------------------------------- G4 / G5
+NAMES_2D = ["g0_0", "g0_1", "g0_2", "g0_3", "g1_0", "g1_1", "g1_2", "g1_3", "pe"]
+
+
+def _check_enc(e, g, prefix, k0, k1):
+    for i in range(k0):
+        exact(e.g0[i], g[f"{prefix}g0_{i}"], f"{prefix}g0_{i}")
+    for i in range(k1):
+        exact(e.g1[i], g[f"{prefix}g1_{i}"], f"{prefix}g1_{i}")
+    exact(e.pe, g[f"{prefix}pe"], prefix + "pe")
+
+
+def test_create_g0_g1_2d(golden):
+    g = golden("g0g1_2d")
+    g0, g1 = t(g["nomip_grid0"]), t(g["nomip_grid1"])
+    for tag, tri in (("tri", True), ("sin", False)):
+        e = O.encode_crop(g0, g1, (3, 5), (8, 8), 0.25, 6, use_tri_pe=tri)
+        _check_enc(e, g, f"nomip_{tag}_", 4, 4)
+    e = O.encode_crop(g0, g1, (1, 50), (12, 5), 0.25, 6)
+    _check_enc(e, g, "rect_", 4, 4)
+    grids = [t(g[f"mip_grid{i}"]) for i in range(4)]
+    for k, (fl, mip, S, ox, oy) in enumerate(g["mip_cases"]):
+        step = O.step_number_of(int(mip), int(fl))
+        e = O.encode_crop(grids[2 * fl], grids[2 * fl + 1], (int(ox), int(oy)), (int(S), int(S)), step, 6)
+        _check_enc(e, g, f"mip_case{k}_", 4, 4)
+
+
+def test_create_g0_g1_3d(golden):
+    g = golden("g0g1_3d")
+    g0, g1 = t(g["grid0"]), t(g["grid1"])
+    e3 = O.encode_crop(g0, g1, (3, 5, 9), (8, 8, 8), 0.25, 6, method=3)
+    _check_enc(e3, g, "m3_", 8, 8)
+    e4 = O.encode_crop(g0, g1, (3, 5, 9), (8, 8, 8), 0.25, 6, method=4)
+    _check_enc(e4, g, "m4_", 4, 8)
+    # Q1: the reference's trilinear weights are permuted - the textbook switch must differ
+    et = O.encode_crop(g0, g1, (3, 5, 9), (8, 8, 8), 0.25, 6, method=3, textbook_weights=True)
+    assert not np.array_equal(et.g1[3].numpy(), g["m3_g1_3"])
+    grids = [t(g[f"mip_grid{i}"]) for i in range(4)]
+    for k, (fl, mip, S, ox, oy, oz) in enumerate(g["mip_cases"]):
+        step = O.step_number_of(int(mip), int(fl))
+        for m, k0 in ((3, 8), (4, 4)):
+            e = O.encode_crop(grids[2 * fl], grids[2 * fl + 1], (int(ox), int(oy), int(oz)), (int(S),) * 3, step, 6, method=m)
+            _check_enc(e, g, f"mip_case{k}_m{m}_", k0, 8)
+
+
+# ---------------------------------------------------------------------------------------- G6
+def test_decoder_input(golden):
+    g = golden("decoder_input")
+    grids = [t(g[f"d2_grid{i}"]) for i in range(6)]
+    mp = O.create_pyramid_mip_levels(256, 64)
+    for mip in (4, 5):
+        fl = mp[mip]
+        S = 2 ** (8 - mip)
+        for tag, tri in (("tri", True), ("sin", False)):
+            x = O.create_decoder_input(grids[2 * fl], grids[2 * fl + 1], [(0, 0), (0, 0)], (S, S),
+                                       O.step_number_of(mip, fl), mip, 6, use_tri_pe=tri)
+            exact(x, g[f"d2_mip{mip}_{tag}"], f"mip{mip} {tag}")
+    fl = mp[2]
+    x = O.create_decoder_input(grids[2 * fl], grids[2 * fl + 1], [(16, 32)], (16, 16), O.step_number_of(2, fl), 2, 6)
+    exact(x, g["d2_final_mip2_tile"])
+    fl = mp[3]
+    x = O.create_decoder_input(grids[2 * fl], grids[2 * fl + 1], [(0, 0)], (32, 32), O.step_number_of(3, fl), 3, 6)
+    exact(x, g["d2_final_mip3_full"])
+    # default training shape: two 256 x 256 crops at mip 0
+    x = O.create_decoder_input(t(g["d2m0_grid0"]), t(g["d2m0_grid1"]), g["d2m0_coord"], (256, 256), 0.25, 0, 6)
+    assert list(x.shape) == list(g["d2m0_shape"])
+    exact(x[t(g["d2m0_rows"])], g["d2m0_sample"])
+    digest_close(O.digest(x), g["d2m0_digest"], 1e-12)
+    # 3D
+    g0, g1 = t(g["d3_grid0"]), t(g["d3_grid1"])
+    for m in (3, 4):
+        x = O.create_decoder_input(g0, g1, g["d3_coord"], (8, 8, 8), 0.25, 0, 6, method=m)
+        exact(x, g[f"d3_m{m}"], f"3d m{m}")
+        assert x.shape[1] == O.decoder_input_channels(2, 6, 3, m)
+        x = O.create_decoder_input(g0, g1, [(8, 20, 60)], (4, 4, 4), 0.25, 0, 6, method=m)
+        exact(x, g[f"d3_final_m{m}"])
+
+
+# ---------------------------------------------------------------------------------------- G7 / G8
+CASES = {"d2": dict(method=1, extent=lambda mip: (2 ** (8 - mip),) * 2),
+         "d3m3": dict(method=3, extent=lambda mip: (4, 4, 4)),
+         "d3m4": dict(method=4, extent=lambda mip: (4, 4, 4))}
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_forward_backward(golden, tag):
+    g = golden("fwdbwd")
+    c = CASES[tag]
+    fl, mip = (int(v) for v in g[f"{tag}_fl_mip"])
+    mlp = O.MLPParams.from_state_dict({k[len(tag) + 4:]: g[k] for k in g if k.startswith(f"{tag}_sd_")})
+    g0, g1 = t(g[f"{tag}_grid_g0"]), t(g[f"{tag}_grid_g1"])
+    step = O.step_number_of(mip, fl)
+    x = O.create_decoder_input(g0, g1, g[f"{tag}_coord"], c["extent"](mip), step, mip, 6, method=c["method"])
+    exact(x, g[f"{tag}_x"], "decoder input")
+    close(O.mlp_forward(x, mlp), g[f"{tag}_y_clean"], 1e-5, 1e-6, "clean forward")
+    r = O.forward_backward(g0, g1, mlp, g[f"{tag}_coord"], c["extent"](mip), step, mip, t(g[f"{tag}_target"]),
+                           t(g[f"{tag}_noise"]), 6, method=c["method"])
+    close(r.y, g[f"{tag}_y"], 1e-5, 1e-6, "noisy forward")
+    close(r.loss, g[f"{tag}_loss"], 1e-6, 0, "loss")
+    close(r.grad_g0, g[f"{tag}_grad_g0"], 1e-4, 1e-9, "grad g0")
+    close(r.grad_g1, g[f"{tag}_grad_g1"], 1e-4, 1e-9, "grad g1")
+    names = ["decoder.0.weight", "decoder.0.bias", "decoder.2.weight", "decoder.2.bias", "decoder.4.weight", "decoder.4.bias"]
+    for n, gr in zip(names, r.grad_mlp):
+        close(gr, g[f"{tag}_grad_{n}"], 1e-4, 1e-8, n)
+
+
+@pytest.mark.parametrize("tag,tri", [("tri", True), ("sin", False)])
+def test_forward_backward_default_shape(golden, tag, tri):
+    """2D, no-mip, C = 12, two 256 x 256 crops: inputs re-drawn from the torch CPU stream the
+    generator used, outputs pinned by digests / row samples / all decoder gradients."""
+    g = golden("fwdbwd_mip0")
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    fp, _ = O.create_pyramid(64, 12, 8, no_mip=True)
+    dg = np.stack([O.digest(fp[0]), O.digest(fp[1])])
+    if not np.allclose(dg, g[f"{tag}_grid_digest"], rtol=1e-12):
+        pytest.skip("torch CPU RNG stream differs from the one the fixture was drawn with")
+    mlp = O.init_mlp(73)
+    N = 2 * 256 * 256
+    origins = [(0, 0), (0, 0)]
+    x = O.create_decoder_input(fp[0].detach(), fp[1].detach(), origins, (256, 256), 0.25, 0, 6, use_tri_pe=tri)
+    digest_close(O.digest(x), g[f"{tag}_x_digest"], 1e-12, "x")
+    exact(x[t(g[f"{tag}_rows"])], g[f"{tag}_x_rows"])
+    noise = (torch.rand_like(x) - 0.5) / 2 ** 8
+    target = torch.rand(N, 3)
+    digest_close(O.digest(noise), g[f"{tag}_noise_digest"], 1e-12, "noise")
+    digest_close(O.digest(target), g[f"{tag}_target_digest"], 1e-12, "target")
+    r = O.forward_backward(fp[0], fp[1], mlp, origins, (256, 256), 0.25, 0, target, noise, 6, use_tri_pe=tri)
+    close(r.y[t(g[f"{tag}_rows"])], g[f"{tag}_y_rows"], 1e-5, 1e-6)
+    digest_close(O.digest(r.y), g[f"{tag}_y_digest"], 1e-6, "y")
+    close(r.loss, g[f"{tag}_loss"], 1e-6)
+    digest_close(O.digest(r.grad_g0), g[f"{tag}_grad_g0_digest"], 1e-4, "grad g0")
+    digest_close(O.digest(r.grad_g1), g[f"{tag}_grad_g1_digest"], 1e-4, "grad g1")
+    close(r.grad_g0[0], g[f"{tag}_grad_g0_c0"], 1e-4, 1e-10)
+    close(r.grad_g1[11], g[f"{tag}_grad_g1_c11"], 1e-4, 1e-10)
+    names = ["decoder.0.weight", "decoder.0.bias", "decoder.2.weight", "decoder.2.bias", "decoder.4.weight", "decoder.4.bias"]
+    for n, gr in zip(names, r.grad_mlp):
+        close(gr, g[f"{tag}_grad_{n}"], 2e-4, 1e-8, n)
+
+
+# ---------------------------------------------------------------------------------------- G9
+def test_codec(golden):
+    g = golden("codec")
+    x = t(g["kat_in"])
+    exact(O.save4fp(x, 8), g["kat_save8"])
+    assert list(g["kat_save8"]) == [0, 63, 127, 128, 191, 254, 255]
+    exact(O.load4fp(O.save4fp(x, 8), 8), g["kat_load8"])
+    exact(O.quantize4fp(x, 8), g["kat_q4fp8"])
+    for b in (2, 4, 8):
+        a = t(g[f"ladder{b}_in"])
+        exact(O.quantize4fp(a, b), g[f"ladder{b}_q4fp"])
+        exact(O.save4fp(a, b), g[f"ladder{b}_save"])
+        exact(O.load4fp(O.save4fp(a, b), b), g[f"ladder{b}_load"])
+        exact(O.quantize_clamp(a * 1.5, b), g[f"ladder{b}_clamp"])
+    u = t(g["u"])
+    exact(O.quantize(u, 8), g["u_quantize8"])
+    exact(O.quantize_to_bit(u, 8), g["u_to_bit8"])
+    exact(O.quantize_to_bit(u.numpy(), 8), g["u_np_to_bit8"])
+    exact(O.quantize_from_bit_to_bit(u.numpy() * 255, 8), g["u_from_bit_to_bit"])
+    assert abs(float(g["psnr_kat"]) - 51.1751) < 1e-3
+    close(O.calculate_psnr(torch.tensor([0., 10.]), torch.tensor([1., 10.])), g["psnr_kat"], 1e-7)
+    a, b = t(g["psnr_a"]), t(g["psnr_b"])
+    close(O.calculate_psnr(O.quantize_to_bit(a, 8), O.quantize_to_bit(b, 8)), g["psnr_torch"], 1e-6)
+    close(O.calculate_psnr(a.numpy() * 255, b.numpy() * 255), g["psnr_np"], 1e-6)
+    close(O.calculate_psnr(a, b, 10), g["psnr_bits10"], 1e-6)
+    fp = [t(g[f"fp_grid{i}"]) for i in range(4)]
+    for i, s in enumerate(O.fp_savable(fp, 4)):
+        exact(s, g[f"fp_sav{i}"])
+    for i, s in enumerate(O.fp_load(O.fp_savable(fp, 4), 4)):
+        exact(s, g[f"fp_load{i}"])
+    for i, s in enumerate(O.fp_all_quantize(fp, 4)):
+        exact(s, g[f"fp_allq{i}"])
+    big = [(f * 1.3).clone() for f in fp]
+    O.fp_quantize_clamp(big, 1, 4)
+    for i, s in enumerate(big):
+        exact(s, g[f"fp_clamp1_{i}"])
+    for b, q in zip(g["q_range_bits"], g["q_min"]):
+        assert O.q_range(int(b)) == (q, 0.5)
+    assert O.q_range(8)[0] == -0.498046875
+
+
+# ---------------------------------------------------------------------------------------- G10
+@pytest.mark.parametrize("tag", ["d3m3", "d3m4", "d2mip"])
+def test_training_trajectory(golden, tag):
+    """Replays the reference's train_models run: same python-random and torch CPU streams, same
+    sampler, noise, Adam, cosine schedule, clamp, freeze + quantise order."""
+    g = golden("trajectory")
+    (image_size, D, method, crop_mip, num_crops, C, epochs, max_mip, no_mip, tri_pe) = (int(v) for v in g[f"{tag}_cfg"])
+    cfg = O.TrainConfig(IMAGE_SIZE=image_size, IMAGE_DIMENSION=D, COMPRESSION_METHOD=method, MAX_MIP_LEVEL=max_mip,
+                        FEATURE_PYRAMID_CHANNELS=C, CROP_MIP_LEVEL=crop_mip, NUM_CROPS=num_crops, NUM_EPOCHS=epochs,
+                        UNIFORM_DISTRIBUTION_RATE=float(g[f"{tag}_uniform_rate"]), TF_NO_MIP=bool(no_mip), TF_USE_TRI_PE=bool(tri_pe))
+    seed = int(g[f"{tag}_seed"])
+    torch.manual_seed(seed)
+    random.seed(seed)
+    base = torch.rand(3, *([image_size] * D))
+    if not np.allclose(O.digest(base), g[f"{tag}_image_digest"], rtol=1e-12):
+        pytest.skip("torch CPU RNG stream differs from the one the fixture was drawn with")
+    images = []
+    for i in range(cfg.MAX_MIP_LEVEL + 1):
+        f = 2 ** i
+        images.append(base.reshape(3, image_size // f, f, image_size // f, f).mean(dim=(2, 4)) if (D == 2 and f > 1) else base)
+    mlp = O.init_mlp(cfg.DECODER_INPUT_CHANNELS, cfg.HIDDEN_LAYER_CHANNELS)
+    fp, _ = O.create_pyramid(cfg.FEATURE_PYRAMID_SIZE, C, cfg.FP_BITS, dim=D, no_mip=cfg.TF_NO_MIP)
+    for i, gr in enumerate(fp):
+        exact(gr.detach(), g[f"{tag}_init_grid{i}"], "initial grid")
+    exact(mlp.w[0], g[f"{tag}_init_sd_decoder.0.weight"])
+    exact(mlp.b[2], g[f"{tag}_init_sd_decoder.4.bias"])
+    exact(torch.rand(1), g[f"{tag}_rng_state_marker"])
+    rec = []
+    losses = O.train_loop(cfg, images, fp, mlp, record=lambda e, lod, coord, loss: rec.append((lod, coord.clone())))
+    assert [r[0] for r in rec] == list(g[f"{tag}_lod"])
+    exact(torch.stack([r[1] for r in rec]), g[f"{tag}_coord"])
+    close(np.array(losses), g[f"{tag}_loss"], 2e-4, 1e-7, "loss trajectory")
+    for i, gr in enumerate(fp):
+        close(gr.detach(), g[f"{tag}_final_grid{i}"], 1e-3, 2e-4, f"final grid {i}")
+    for k, v in zip(["decoder.0.weight", "decoder.0.bias", "decoder.2.weight", "decoder.2.bias", "decoder.4.weight", "decoder.4.bias"], mlp.tensors()):
+        close(v.detach(), g[f"{tag}_final_sd_{k}"], 1e-3, 2e-4, k)
+    # decode on the quantised pyramid, PSNR (peak 256) within 0.01 dB of the reference's own figure
+    cfg_dec = cfg
+    img = O.decode_image(O.fp_all_quantize([f.detach() for f in fp], cfg.FP_BITS), mlp, cfg_dec, 0)
+    flat = img.reshape(-1, 3)
+    close(flat[:: max(1, flat.shape[0] // 512)], g[f"{tag}_decoded_mip0_rows"], 1e-2, 2e-3, "decoded rows")
+    perm = (1, 2, 0) if D == 2 else (1, 2, 3, 0)
+    psnr = O.calculate_psnr(O.quantize_to_bit(img, 8), O.quantize_to_bit(images[0].permute(*perm), 8))
+    assert abs(float(psnr) - float(g[f"{tag}_psnr_mip0"])) < 0.01
+
+
+# ---------------------------------------------------------------------------------------- philox
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32-10
+    z = O.philox4x32_10(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]
+    assert [hex(v) for v in z] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f = O.philox4x32_10(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [hex(v) for v in f] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    p = O.philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], dtype=np.uint32), (0xa4093822, 0x299f31d0))[0]
+    assert [hex(v) for v in p] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_philox_noise_statistics():
+    n = O.philox_noise(4096, 73, 8, seed=7, offset=3)
+    assert n.shape == (4096, 73) and n.dtype == torch.float32
+    assert float(n.abs().max()) < 0.5 / 256
+    assert abs(float(n.mean())) < 2e-5
+    assert abs(float(n.var()) - (1 / 256) ** 2 / 12) < 1e-7
+    # different offsets / seeds / sample bases give different streams; sample_base is a pure shift
+    assert not torch.equal(n, O.philox_noise(4096, 73, 8, seed=7, offset=4))
+    assert not torch.equal(n, O.philox_noise(4096, 73, 8, seed=8, offset=3))
+    assert torch.equal(n[100:200], O.philox_noise(100, 73, 8, seed=7, offset=3, sample_base=100))
