@@ -1,0 +1,190 @@
+/*
+ * nicv2_hip.h - C ABI of the MI355X (gfx950) implementation of the reference's per-sample hot path:
+ *               feature-grid gather + positional encoding + tiny GELU MLP, forward and backward.
+ *
+ * The reference (21K1113/Neural_Image_Compression_V2) is pure Python and has no FFI of its own; the
+ * boundary is the Python call surface of Projects/fp_def.py, Projects/utils.py, Projects/models.py and
+ * the create_decoder_input / ColorDecoder / decode_image part of Projects/image_compression.py.
+ * Every entry point below names the reference lines it replaces.  The host mirror of those Python
+ * signatures lives in neural_image_compression_v2_amd/ and binds this library with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; tensors are dense fp32.
+ *  - a grid is [C, (Z,) Y, X] like the reference (fp_def.py:54,76); the FIRST sample axis ("x",
+ *    coord[0]) walks the LAST grid axis (fp_def.py:81-112).  All per-axis arrays in this header are
+ *    given in sample-axis order (x, y, z).
+ *  - samples of a crop are numbered x-outer ... z-inner, crops back to back (fp_def.py:124-129,
+ *    image_compression.py:97); N = num_crops * extent[0] * extent[1] * extent[2].
+ *  - decoder weights are nn.Linear layout [out, in] row-major (image_compression.py:57-64).
+ *  - all functions are asynchronous on `stream` (a hipStream_t passed as void*), allocate nothing and
+ *    never synchronise, so a caller may capture them into a hipGraph.
+ *  - return value: 0 on success, a positive hipError_t from the runtime, or a negative NIC_E_* code.
+ */
+#ifndef NICV2_HIP_H
+#define NICV2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIC_ABI_VERSION 1
+
+enum {
+    NIC_OK = 0,
+    NIC_E_NULL = -1,        /* required pointer is null */
+    NIC_E_UNSUPPORTED = -2, /* dim / method / channels / hidden combination has no kernel */
+    NIC_E_SHAPE = -3,       /* extents, node counts or origins inconsistent (index would leave the grid) */
+    NIC_E_WORKSPACE = -4,   /* workspace smaller than nic_workspace_bytes() */
+    NIC_E_ARG = -5          /* other invalid argument */
+};
+
+/* pe_mode */
+enum { NIC_PE_TRIANGULAR = 0 /* utils.py:211-227 */, NIC_PE_SINUSOIDAL = 1 /* utils.py:198-208 */ };
+/* g1_weight_mode */
+enum {
+    NIC_G1_REFERENCE = 0,  /* bilinear in 2D; the reference's permuted trilinear products in 3D (fp_def.py:176-183) */
+    NIC_G1_TEXTBOOK = 1,   /* true trilinear */
+    NIC_G1_UNWEIGHTED = 2  /* plain corner sum: what the reference does when step_number == 2 (fp_def.py:136) */
+};
+/* noise_mode */
+enum {
+    NIC_NOISE_NONE = 0,
+    NIC_NOISE_TENSOR = 1,  /* caller supplies the [N, Cin] noise (parity with torch.rand_like, image_compression.py:250) */
+    NIC_NOISE_PHILOX = 2   /* generated in-kernel, Philox-4x32-10 keyed by (seed, offset, global sample id, channel) */
+};
+
+/* Geometry of one launch: which grid pair, which samples.  Mirrors the arguments of
+ * create_g0_g1 / create_g0_g1_3d / create_g0_g1_3d_v2 (fp_def.py:115,148,187) and of
+ * create_decoder_input_2d/_3d/_3d_v2 (image_compression.py:71,103,137). */
+typedef struct nic_path_desc {
+    int32_t dim;             /* 2 or 3 */
+    int32_t method;          /* 1: 2D.  3: 3D, 8 raw G0 corners.  4: 3D, 4 tetrahedral G0 corners (fp_def.py:107-112) */
+    int32_t channels;        /* FEATURE_PYRAMID_CHANNELS (var2.py:68) */
+    int32_t pe_channels;     /* PE_CHANNELS (var2.py:69) */
+    int32_t hidden;          /* HIDDEN_LAYER_CHANNELS (var2.py:72) */
+    int32_t pe_mode;         /* NIC_PE_* */
+    int32_t g1_weight_mode;  /* NIC_G1_* */
+    int32_t log2_step;       /* step_number = 2^log2_step = 2^(mip - 2(fl+1))  (image_compression.py:79) */
+    float lod_value;         /* value of the LOD channel = mip_level (image_compression.py:95) */
+    int32_t num_crops;
+    int32_t extent[3];       /* samples per axis of one crop (sample_number); extent[2] = 1 in 2D */
+    int32_t g0_nodes[3];     /* nodes per axis of G0 = fp[2*fl]  (x, y, z order) */
+    int32_t g1_nodes[3];     /* nodes per axis of G1 = fp[2*fl+1] */
+    float pe_div[8];         /* sinusoidal div_term, fp32, pe_channels/2 entries (utils.py:202) */
+    int32_t noise_mode;      /* NIC_NOISE_* */
+    int32_t num_bits;        /* FP_BITS: noise amplitude 2^-num_bits (image_compression.py:250) */
+    uint64_t philox_seed;
+    uint64_t philox_offset;  /* e.g. the training step */
+    int64_t sample_base;     /* global id of this launch's sample 0 (data-parallel shards: keeps the noise world-size invariant) */
+    float loss_scale;        /* 1 / (3 * N_global): the MSELoss mean (image_compression.py:259) */
+    int32_t reserved;
+} nic_path_desc;
+
+/* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */
+typedef struct nic_mlp {
+    const float *w[3]; /* [H,Cin], [H,H], [3,H] */
+    const float *b[3]; /* [H], [H], [3] */
+} nic_mlp;
+
+typedef struct nic_mlp_grads {
+    float *w[3];
+    float *b[3];
+} nic_mlp_grads;
+
+int nic_abi_version(void);
+const char *nic_error_string(int code);
+
+/* Number of decoder input channels Cin (var2.py:114-118). */
+int nic_decoder_input_channels(int dim, int method, int channels, int pe_channels);
+
+/* Bytes of scratch the *_backward entry points need (per-wave partial sums of the decoder gradients,
+ * reduced in a fixed order by a second kernel so decoder gradients and loss are run-to-run bit-stable). */
+size_t nic_workspace_bytes(const nic_path_desc *desc);
+
+/* ---- encode only: replaces create_decoder_input_2d/_3d/_3d_v2 and finally_decode_input_*
+ *      (image_compression.py:71-211).  out = [N, Cin].  origins = int32 [num_crops, dim]. */
+int nic_encode(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+               float *out, void *stream);
+
+/* ---- autograd backward of nic_encode: dx = [N, Cin] -> scatter-add into g0_grad / g1_grad (shapes of g0 / g1, NOT
+ *      zeroed here: fp32 atomic adds, the reference's index_put_(accumulate=True) from loss.backward(),
+ *      image_compression.py:265).  The PE and LOD columns of dx have no parameters behind them and are ignored. */
+int nic_encode_backward(const nic_path_desc *desc, const int32_t *origins, const float *dx, float *g0_grad,
+                        float *g1_grad, void *stream);
+
+/* ---- encode, split outputs: replaces create_g0_g1 / _3d / _3d_v2 (fp_def.py:115-223) for ONE crop.
+ *      out = [K0*C + K1*C + P*dim, n] rows: raw G0 corners, weighted G1 corners (not summed), PE. */
+int nic_encode_split(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                     float *out, void *stream);
+
+/* ---- corner gathers on explicit index vectors: replaces create_g / create_g_3d / create_g_3d_v2 (fp_def.py:81-112).
+ *      grid = [C, (nz,) ny, nx]; xi / yi / zi = int32 [n] (zi null in 2D); corner_set 0: the 4 corners of 2D,
+ *      1: the 8 corners of 3D, 2: the 4 tetrahedral corners; out = [K, C, n] in the reference's corner order.
+ *      Indices are clamped into the grid (the reference would raise IndexError). */
+int nic_gather_corners(const float *grid, int channels, int nx, int ny, int nz, const int32_t *xi, const int32_t *yi,
+                       const int32_t *zi, int64_t n, int corner_set, float *out, void *stream);
+
+/* ---- positional encodings on explicit coordinates (utils.py:198-227).  coord = [dim, n], out = [P*dim, n]. */
+int nic_positional_encoding(const float *coord, int64_t n, int dim, int pe_channels, int pe_mode,
+                            const float *pe_div_host, float *out, void *stream);
+
+/* ---- LUT positional encoding gather: replaces TriangularPositionalEncoding1D.forward
+ *      (positional_encoding.py:36-42).  lut = [rows, seq_len], coord = int64 [b, L], out = [b, rows, L]. */
+int nic_lut_gather(const float *lut, int rows, int seq_len, const int64_t *coord, int64_t b, int64_t L,
+                   float *out, void *stream);
+
+/* ---- decoder on explicit inputs: replaces ColorDecoder.forward (image_compression.py:66-68).
+ *      x = [n, cin], y = [n, 3]. */
+int nic_decoder_forward(const nic_mlp *mlp, const float *x, int64_t n, int cin, int hidden, float *y, void *stream);
+
+/* ---- its autograd backward: dy = [n,3] -> dx = [n,cin] (may be null) and the six parameter gradients
+ *      (overwritten, not accumulated). */
+int nic_decoder_backward(const nic_mlp *mlp, const float *x, const float *dy, int64_t n, int cin, int hidden,
+                         float *dx, const nic_mlp_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- fused inference: encode + (optional noise) + decoder.  Replaces finally_decode_input_* + arc_decoder(x)
+ *      inside decode_image (image_compression.py:313-345).  y = [N, 3]. */
+int nic_fused_forward(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                      const nic_mlp *mlp, const float *noise, float *y, void *stream);
+
+/* ---- fused training step core: encode + noise + decoder + MSE loss + full backward.  Replaces
+ *      image_compression.py:239-265 (create_decoder_input_*, rand_like noise, decoder(...), MSELoss, backward).
+ *      target = [N,3].  y may be null.  loss = 1 float (the mean, desc->loss_scale * sum of squared error).
+ *      g0_grad / g1_grad have the shapes of g0 / g1 and must be ZEROED by the caller (the kernel adds into
+ *      them with fp32 atomics, like index_put_(accumulate=True)); decoder gradients and loss are overwritten. */
+int nic_fused_forward_backward(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                               const nic_mlp *mlp, const float *noise, const float *target, float *y, float *loss,
+                               float *g0_grad, float *g1_grad, const nic_mlp_grads *grads,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- same, for an arbitrary upstream gradient dy = [N,3] instead of the built-in MSE (autograd backward of
+ *      nic_fused_forward; the forward is recomputed). */
+int nic_fused_backward_dy(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                          const nic_mlp *mlp, const float *noise, const float *dy,
+                          float *g0_grad, float *g1_grad, const nic_mlp_grads *grads,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- quantisers / codec (models.py:55-71, fp_def.py:227-263).  In-place allowed (dst == src). */
+int nic_quantize(const float *src, float *dst, int64_t n, int num_bits, void *stream);              /* floor(x*(2^b-1)+.5)/(2^b-1) */
+int nic_quantize_to_bit(const float *src, float *dst, int64_t n, int num_bits, void *stream);       /* models.py:39-40 */
+int nic_clamp(float *x, int64_t n, float lo, float hi, void *stream);                                /* fp_quantize_clamp */
+int nic_save4fp_u8(const float *src, uint8_t *dst, int64_t n, int num_bits, void *stream);          /* models.py:61-64 */
+int nic_load4fp_u8(const uint8_t *src, float *dst, int64_t n, int num_bits, void *stream);          /* models.py:68-71 */
+
+/* ---- PSNR with peak = 2^num_bits (utils.py:117-130): out[0] = mse, out[1] = psnr dB (inf when mse == 0). */
+int nic_psnr(const float *a, const float *b, int64_t n, int num_bits, float *out2, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- fused Adam step + in-place clamp for one parameter tensor (image_compression.py:266-269, 361-365):
+ *      torch.optim.Adam semantics (no weight decay, no amsgrad), bias-corrected with step count `step` (1-based).
+ *      clamp_lo > clamp_hi disables the clamp. */
+int nic_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int64_t step, float clamp_lo, float clamp_hi, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NICV2_HIP_H */

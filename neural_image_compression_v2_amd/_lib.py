@@ -1,0 +1,138 @@
+"""ctypes binding of libnicv2_hip.so (C ABI: include/nicv2_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the caller gets a
+RuntimeError.  Nothing in this package computes the hot path on the CPU or through eager torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+import torch  # imported before the library so libamdhip64.so.7 resolves to the runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnicv2_hip.so")
+
+NIC_ABI_VERSION = 1
+NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
+NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
+NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_PHILOX = 0, 1, 2
+
+
+class NicPathDesc(ctypes.Structure):
+    """struct nic_path_desc (include/nicv2_hip.h)."""
+    _fields_ = [
+        ("dim", ctypes.c_int32), ("method", ctypes.c_int32), ("channels", ctypes.c_int32),
+        ("pe_channels", ctypes.c_int32), ("hidden", ctypes.c_int32), ("pe_mode", ctypes.c_int32),
+        ("g1_weight_mode", ctypes.c_int32), ("log2_step", ctypes.c_int32), ("lod_value", ctypes.c_float),
+        ("num_crops", ctypes.c_int32), ("extent", ctypes.c_int32 * 3), ("g0_nodes", ctypes.c_int32 * 3),
+        ("g1_nodes", ctypes.c_int32 * 3), ("pe_div", ctypes.c_float * 8), ("noise_mode", ctypes.c_int32),
+        ("num_bits", ctypes.c_int32), ("philox_seed", ctypes.c_uint64), ("philox_offset", ctypes.c_uint64),
+        ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("reserved", ctypes.c_int32),
+    ]
+
+
+class NicMlp(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3)]
+
+
+class NicMlpGrads(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3)]
+
+
+_P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_D = ctypes.POINTER(NicPathDesc)
+_M = ctypes.POINTER(NicMlp)
+_G = ctypes.POINTER(NicMlpGrads)
+
+# name -> (restype, argtypes): every symbol include/nicv2_hip.h declares
+SIGNATURES = {
+    "nic_abi_version": (_I, []),
+    "nic_error_string": (ctypes.c_char_p, [_I]),
+    "nic_decoder_input_channels": (_I, [_I, _I, _I, _I]),
+    "nic_workspace_bytes": (_SZ, [_D]),
+    "nic_encode": (_I, [_D, _P, _P, _P, _P, _P]),
+    "nic_encode_split": (_I, [_D, _P, _P, _P, _P, _P]),
+    "nic_encode_backward": (_I, [_D, _P, _P, _P, _P, _P]),
+    "nic_positional_encoding": (_I, [_P, _L, _I, _I, _I, ctypes.POINTER(ctypes.c_float), _P, _P]),
+    "nic_lut_gather": (_I, [_P, _I, _I, _P, _L, _L, _P, _P]),
+    "nic_decoder_forward": (_I, [_M, _P, _L, _I, _I, _P, _P]),
+    "nic_decoder_backward": (_I, [_M, _P, _P, _L, _I, _I, _P, _G, _P, _SZ, _P]),
+    "nic_fused_forward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
+    "nic_fused_forward_backward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _P, _P, _G, _P, _SZ, _P]),
+    "nic_fused_backward_dy": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _G, _P, _SZ, _P]),
+    "nic_quantize": (_I, [_P, _P, _L, _I, _P]),
+    "nic_quantize_to_bit": (_I, [_P, _P, _L, _I, _P]),
+    "nic_clamp": (_I, [_P, _L, _F, _F, _P]),
+    "nic_save4fp_u8": (_I, [_P, _P, _L, _I, _P]),
+    "nic_load4fp_u8": (_I, [_P, _P, _L, _I, _P]),
+    "nic_psnr": (_I, [_P, _P, _L, _I, _P, _P, _SZ, _P]),
+    "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _F, _P]),
+    "nic_gather_corners": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Loads the library (once).  Raises if it has not been built: there is no other implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing - the HIP extension is the only implementation of this path. "
+                    "Build it with `python -m neural_image_compression_v2_amd._build` (hipcc, gfx950).")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if the build is stale: loud by design
+                fn.restype = res
+                fn.argtypes = args
+            if lib.nic_abi_version() != NIC_ABI_VERSION:
+                raise RuntimeError("libnicv2_hip.so ABI version mismatch - rebuild")
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().nic_error_string(int(rc)).decode()
+        raise RuntimeError(f"libnicv2_hip {what} failed: {msg} (code {rc})")
+
+
+def stream_ptr(device: Optional[torch.device] = None) -> ctypes.c_void_p:
+    """the current torch HIP stream as the void* the C ABI takes"""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} lives on {t.device}: this package only runs on a HIP device (no CPU path)")
+    if t.dtype != torch.float32:
+        raise NotImplementedError(f"{name} has dtype {t.dtype}; the gfx950 kernels are fp32 "
+                                  "(the reference's 16-bit path is itself unfinished, readme.md:9)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+_workspaces = {}
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """per (device, stream) scratch buffer, grown on demand; owned by torch's caching allocator"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,216 @@
+// C ABI of the fused encode + decoder kernels (include/nicv2_hip.h): argument checks, launch geometry,
+// workspace bookkeeping.  No allocation, no synchronisation: capture-safe.
+#include "fused_launch.hpp"
+#include <string.h>
+
+using namespace nic;
+
+namespace {
+
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+// layout id (see nic_device.hpp) or a negative error
+int pick_layout(const nic_path_desc* d) {
+    if (!d) return NIC_E_NULL;
+    if (d->channels != kC || d->pe_channels != kP || d->hidden != kH) return NIC_E_UNSUPPORTED;
+    if (d->dim == 2 && d->method == 1) return d->pe_mode == NIC_PE_TRIANGULAR ? 1 : (d->pe_mode == NIC_PE_SINUSOIDAL ? 2 : NIC_E_UNSUPPORTED);
+    if (d->dim == 3 && d->method == 3) return d->pe_mode == NIC_PE_TRIANGULAR ? 3 : NIC_E_UNSUPPORTED;   // fp_def.py:169
+    if (d->dim == 3 && d->method == 4) return d->pe_mode == NIC_PE_SINUSOIDAL ? 4 : NIC_E_UNSUPPORTED;   // fp_def.py:208
+    return NIC_E_UNSUPPORTED;
+}
+int layout_of_cin(int cin) { return cin == 73 ? 1 : (cin == 127 ? 3 : (cin == 79 ? 4 : NIC_E_UNSUPPORTED)); }
+
+FusedInfo info_of(int layout) {
+    switch (layout) {
+        case 1: return fused_info<1>();
+        case 2: return fused_info<2>();
+        case 3: return fused_info<3>();
+        default: return fused_info<4>();
+    }
+}
+int launch(int layout, int src, int mode, const FusedParams& p, int grid, hipStream_t s) {
+    switch (layout) {
+        case 1: return launch_fused<1>(src, mode, p, grid, s);
+        case 2: return launch_fused<2>(src, mode, p, grid, s);
+        case 3: return launch_fused<3>(src, mode, p, grid, s);
+        default: return launch_fused<4>(src, mode, p, grid, s);
+    }
+}
+int reduce(int layout, const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+    switch (layout) {
+        case 1: return launch_reduce<1>(partials, n_waves, g, loss, loss_scale, s);
+        case 2: return launch_reduce<2>(partials, n_waves, g, loss, loss_scale, s);
+        case 3: return launch_reduce<3>(partials, n_waves, g, loss, loss_scale, s);
+        default: return launch_reduce<4>(partials, n_waves, g, loss, loss_scale, s);
+    }
+}
+
+int check_geometry(const nic_path_desc* d) {
+    if (d->num_crops < 1) return NIC_E_SHAPE;
+    for (int a = 0; a < d->dim; ++a)
+        if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
+    if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
+    if (d->g1_weight_mode < 0 || d->g1_weight_mode > 2 || d->noise_mode < 0 || d->noise_mode > 2) return NIC_E_ARG;
+    return NIC_OK;
+}
+
+// persistent grid: a multiple of 8 blocks (one slice of the tile range per XCD), at most `per_cu` per CU
+int grid_for(int64_t n_tiles, int per_cu) {
+    int64_t want = (n_tiles + 3) / 4;                 // 4 waves per block, one tile each
+    want = (want + 7) / 8 * 8;
+    const int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
+    if (want > cap) want = cap;
+    if (want < 8) want = 8;
+    return (int)want;
+}
+
+void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, const float* g0, const float* g1, const int32_t* origins,
+                 const float* noise) {
+    p.d = *d;
+    p.g0.p = g0; p.g0.nx = d->g0_nodes[0]; p.g0.ny = d->g0_nodes[1]; p.g0.nz = d->dim == 3 ? d->g0_nodes[2] : 1;
+    p.g0.plane = (int64_t)p.g0.nx * p.g0.ny * p.g0.nz;
+    p.g1.p = g1; p.g1.nx = d->g1_nodes[0]; p.g1.ny = d->g1_nodes[1]; p.g1.nz = d->dim == 3 ? d->g1_nodes[2] : 1;
+    p.g1.plane = (int64_t)p.g1.nx * p.g1.ny * p.g1.nz;
+    p.origins = origins;
+    const int ez = d->dim == 3 ? d->extent[2] : 1;
+    p.d.extent[2] = ez;
+    p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * ez;
+    p.n_total = p.n_per_crop * d->num_crops;
+    const int tx = (d->extent[0] + fi.tx - 1) / fi.tx, ty = (d->extent[1] + fi.ty - 1) / fi.ty, tz = (ez + fi.tz - 1) / fi.tz;
+    p.tiles_y = ty; p.tiles_z = tz;
+    p.tiles_per_crop = (int64_t)tx * ty * tz;
+    p.n_tiles = p.tiles_per_crop * d->num_crops;
+    p.noise.mode = d->noise_mode;
+    p.noise.tensor = noise;
+    p.noise.k0 = (uint32_t)d->philox_seed; p.noise.k1 = (uint32_t)(d->philox_seed >> 32);
+    p.noise.off_lo = (uint32_t)d->philox_offset; p.noise.off_hi = (uint32_t)(d->philox_offset >> 32);
+    p.noise.scale = ldexpf(1.0f, -d->num_bits);
+    p.grad_scale = 2.0f * d->loss_scale;
+}
+void fill_mlp(FusedParams& p, const nic_mlp* m) {
+    for (int i = 0; i < 3; ++i) { p.W[i] = m->w[i]; p.b[i] = m->b[i]; }
+}
+bool mlp_ok(const nic_mlp* m) {
+    if (!m) return false;
+    for (int i = 0; i < 3; ++i) if (!m->w[i] || !m->b[i]) return false;
+    return true;
+}
+FusedParams zero_params() {
+    FusedParams p;
+    ::memset(static_cast<void*>(&p), 0, sizeof(p));
+    return p;
+}
+
+int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp, const float* noise,
+                const float* target, const float* dy, float* y, float* loss, float* g0_grad, float* g1_grad, const nic_mlp_grads* grads,
+                void* workspace, size_t workspace_bytes, void* stream) {
+    const int layout = pick_layout(d);
+    if (layout < 0) return layout;
+    int rc = check_geometry(d);
+    if (rc) return rc;
+    if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !g0_grad || !g1_grad || !grads || !workspace) return NIC_E_NULL;
+    if ((target == nullptr) == (dy == nullptr)) return NIC_E_ARG;
+    if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
+    const FusedInfo fi = info_of(layout);
+    FusedParams p = zero_params();
+    fill_encode(p, d, fi, g0, g1, origins, noise);
+    fill_mlp(p, mlp);
+    p.g0_grad = g0_grad; p.g1_grad = g1_grad;
+    p.target = target; p.dy = dy; p.y = y;
+    p.partials = (float*)workspace;
+    const int grid = grid_for(p.n_tiles, 1);
+    if (workspace_bytes < (size_t)grid * 4 * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch(layout, SRC_ENCODE, target ? MODE_TRAIN_MSE : MODE_TRAIN_DY, p, grid, s);
+    if (rc) return rc;
+    return reduce(layout, p.partials, grid * 4, *grads, target ? loss : nullptr, d->loss_scale, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nic_workspace_bytes(const nic_path_desc* d) {
+    int rec = fused_info<3>().rec;                                   // the largest record
+    if (d) {
+        const int layout = pick_layout(d);
+        if (layout > 0) rec = info_of(layout).rec;
+    }
+    const size_t waves = (size_t)(cu_count() / 8 * 8) * 4;
+    const size_t fused = waves * rec * sizeof(float);
+    const size_t psnr = 1024 * sizeof(double);
+    return fused > psnr ? fused : psnr;
+}
+
+int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
+                      const float* noise, float* y, void* stream) {
+    const int layout = pick_layout(d);
+    if (layout < 0) return layout;
+    int rc = check_geometry(d);
+    if (rc) return rc;
+    if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
+    if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
+    const FusedInfo fi = info_of(layout);
+    FusedParams p = zero_params();
+    fill_encode(p, d, fi, g0, g1, origins, noise);
+    fill_mlp(p, mlp);
+    p.y = y;
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
+}
+
+int nic_fused_forward_backward(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
+                               const float* noise, const float* target, float* y, float* loss, float* g0_grad, float* g1_grad,
+                               const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!target || !loss) return NIC_E_NULL;
+    return fused_train(d, g0, g1, origins, mlp, noise, target, nullptr, y, loss, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream);
+}
+
+int nic_fused_backward_dy(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
+                          const float* noise, const float* dy, float* g0_grad, float* g1_grad, const nic_mlp_grads* grads,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy) return NIC_E_NULL;
+    return fused_train(d, g0, g1, origins, mlp, noise, nullptr, dy, nullptr, nullptr, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream);
+}
+
+int nic_decoder_forward(const nic_mlp* mlp, const float* x, int64_t n, int cin, int hidden, float* y, void* stream) {
+    if (!mlp_ok(mlp) || !x || !y) return NIC_E_NULL;
+    if (hidden != kH) return NIC_E_UNSUPPORTED;
+    const int layout = layout_of_cin(cin);
+    if (layout < 0) return layout;
+    if (n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    FusedParams p = zero_params();
+    fill_mlp(p, mlp);
+    p.x = x; p.y = y; p.n_total = n; p.n_tiles = (n + 31) / 32;
+    return launch(layout, SRC_MEMORY, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
+}
+
+int nic_decoder_backward(const nic_mlp* mlp, const float* x, const float* dy, int64_t n, int cin, int hidden, float* dx,
+                         const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!mlp_ok(mlp) || !x || !dy || !grads || !workspace) return NIC_E_NULL;
+    if (hidden != kH) return NIC_E_UNSUPPORTED;
+    const int layout = layout_of_cin(cin);
+    if (layout < 0) return layout;
+    if (n <= 0) return NIC_E_ARG;
+    const FusedInfo fi = info_of(layout);
+    FusedParams p = zero_params();
+    fill_mlp(p, mlp);
+    p.x = x; p.dy = dy; p.dx = dx; p.n_total = n; p.n_tiles = (n + 31) / 32;
+    p.partials = (float*)workspace;
+    const int grid = grid_for(p.n_tiles, 1);
+    if (workspace_bytes < (size_t)grid * 4 * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = launch(layout, SRC_MEMORY, MODE_TRAIN_DY, p, grid, s);
+    if (rc) return rc;
+    return reduce(layout, p.partials, grid * 4, *grads, nullptr, 0.f, s);
+}
+
+}  // extern "C"

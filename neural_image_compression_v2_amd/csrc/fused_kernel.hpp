@@ -1,0 +1,737 @@
+// Fused encode + decoder MLP forward / backward for gfx950 (CDNA4), fp32 in / fp32 accumulate on the
+// exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Work decomposition
+//   * one wave = one tile of 32 samples at a time; a 256-thread workgroup is 4 independent waves that
+//     only share the decoder weights in LDS (no workgroup barrier inside the tile loop);
+//   * persistent grid (<= 1 workgroup per CU for training: the wave keeps every decoder-gradient
+//     accumulator tile in its accumulator registers for the whole launch), XCD-aware tile order:
+//     blocks b and b+8 share an XCD / L2, so each XCD walks one contiguous range of tiles and
+//     neighbouring tiles re-use the same grid cells out of that XCD's L2;
+//   * sample-on-lane orientation: every activation matrix is [features, 32 samples] with the sample
+//     on the MFMA column (lane & 31).  A 32x32 accumulator register r of lane-half h then holds
+//     feature row ROW(r,h) of the lane's own sample, which is precisely the B operand the next
+//     layer's MFMA wants (k-step = register index): the three forward layers and the two backward
+//     dA products chain through registers with no LDS traffic.  Only the weight-gradient products,
+//     which contract over the sample index, go through a transposed wave-private LDS image.
+//   * the input gradient leaves the last backward product in the registers of the lane that computed
+//     the corresponding grid address in the forward pass; it is scattered with fp32 atomics
+//     (the reference's index_put_(accumulate=True), image_compression.py:265).
+//   * decoder-gradient accumulators are written once per wave to a workspace and summed in a fixed
+//     order by reduce_partials_kernel (bit-stable decoder gradients and loss).
+#pragma once
+#include "nic_device.hpp"
+
+namespace nic {
+
+enum { SRC_ENCODE = 0, SRC_MEMORY = 1 };
+enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2 };
+
+struct FusedParams {
+    nic_path_desc d;
+    GridView g0, g1;
+    float* g0_grad;
+    float* g1_grad;
+    const int32_t* origins;
+    const float* W[3];
+    const float* b[3];
+    NoiseSrc noise;
+    const float* x;        // SRC_MEMORY: [n, cin]
+    float* dx;             // SRC_MEMORY training: [n, cin] or null
+    const float* target;   // MODE_TRAIN_MSE: [N, 3]
+    const float* dy;       // MODE_TRAIN_DY:  [N, 3]
+    float* y;              // [N, 3] or null
+    float* partials;       // workspace, [n_waves][REC]
+    int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;
+    int tiles_y, tiles_z;
+    float grad_scale;      // 2 * loss_scale
+};
+
+template <class L>
+struct Lds {
+    static constexpr int KPAD = 2 * L::NSLOT;
+    static constexpr int KT = (L::NSLOT + 15) / 16;          // 32-row tiles of the padded input
+    static constexpr int LD1 = KPAD + 4;                      // row strides are 4 * odd: conflict-free b128 rows
+    static constexpr int LD2 = kH + 4;
+    static constexpr int LDT = 36;                            // transposed scratch: 32 samples + 4
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_W2 = OFF_W1 + kH * LD1;
+    static constexpr int OFF_W3 = OFF_W2 + kH * LD2;
+    static constexpr int OFF_B2 = OFF_W3 + 4 * LD2;           // W3 rows 0..2 + one zero row (k padding of dA2)
+    static constexpr int OFF_B3 = OFF_B2 + kH;
+    static constexpr int OFF_SCR = OFF_B3 + 16;
+    static constexpr int SCR_PER_WAVE = 128 * LDT;            // SA (64 rows) + SB (64 rows)
+    static constexpr int TOTAL_INFER = OFF_SCR;
+    static constexpr int TOTAL_TRAIN = OFF_SCR + 4 * SCR_PER_WAVE;
+    static constexpr int NACC = 2 * KT + 4;                   // MFMA accumulator tiles: dW1 [2][KT], dW2 [2][2]
+    static constexpr int TAIL = 64 + 192 + 4;                 // db2[64], dW3[3][64], db3[3], loss
+    static constexpr int REC = NACC * 1024 + 320;             // floats per wave in the workspace
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// LDS traffic between lanes of ONE wave: DS operations of a wave complete in order, so only the
+// compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Makes a per-lane LDS base pointer opaque to the optimiser at this point of the tile loop: everything
+// derived from it (base + compile-time constant) stays in the loop body, where instruction selection
+// folds the constant into the DS instruction's 16-bit offset field.  Without this, loop-invariant code
+// motion hoists one VGPR per unrolled LDS access out of the loop (hundreds) and spills them.
+typedef __attribute__((address_space(3))) float lds_f;            // 32-bit LDS pointers: stay DS instructions
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+__device__ __forceinline__ lds_f* opaque(lds_f* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ f32x4 ld4(lds_cf* p) { return *reinterpret_cast<lds_cf4*>(p); }
+__host__ __device__ constexpr int ROWC(int r) { return (r & 3) + 8 * (r >> 2); }   // ROW(r,h) = ROWC(r) + 4h
+
+// what the scatter needs to recompute a slot's grid address
+struct EncCtx {
+    int64_t off0, off1;     // element offsets of corner (0,0,0) in G0 / G1 (channel 0)
+    float kx, ky, kz;       // G1 interpolation fractions
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- G1 interpolation factors.  The reference multiplies corner q by one factor per axis, k or 1-k,
+// chosen by a bit triple (see g1_ref_weight_bits): fx[bit], fy[bit], fz[bit].  NIC_G1_UNWEIGHTED (the
+// reference's step_number == 2 case) is the same arithmetic with every factor = 1, which is bit-identical
+// to not multiplying.  Everything here is selects on launch-uniform flags: no branches in the tile loop.
+struct G1Factors {
+    float fx[2], fy[2], fz[2];
+    uint32_t bits;          // 3 bits per corner q: bx | by<<1 | bz<<2
+};
+template <int DIM>
+__device__ __forceinline__ G1Factors g1_factors(int mode, float kx, float ky, float kz) {
+    G1Factors f;
+    const bool unw = mode == NIC_G1_UNWEIGHTED;
+    f.fx[0] = unw ? 1.0f : 1.0f - kx; f.fx[1] = unw ? 1.0f : kx;
+    f.fy[0] = unw ? 1.0f : 1.0f - ky; f.fy[1] = unw ? 1.0f : ky;
+    f.fz[0] = unw ? 1.0f : 1.0f - kz; f.fz[1] = unw ? 1.0f : kz;
+    // corner offsets: 2D q -> (dx = q>>1, dy = q&1); 3D q -> (dx = q>>2, dy = (q>>1)&1, dz = q&1)
+    constexpr uint32_t nat2 = (0u) | (2u << 3) | (1u << 6) | (3u << 9);
+    constexpr uint32_t nat3 = (0u) | (4u << 3) | (2u << 6) | (6u << 9) | (1u << 12) | (5u << 15) | (3u << 18) | (7u << 21);
+    constexpr uint32_t ref3 = (0u) | (4u << 3) | (2u << 6) | (1u << 9) | (3u << 12) | (5u << 15) | (6u << 18) | (7u << 21);   // Q1
+    f.bits = DIM == 2 ? nat2 : (mode == NIC_G1_REFERENCE ? ref3 : nat3);
+    return f;
+}
+template <int DIM>
+__device__ __forceinline__ float g1_corner_factor(const G1Factors& f, int q) {      // d(blend)/d(corner q)
+    const uint32_t b = (f.bits >> (3 * q)) & 7u;
+    float w = ((b & 1u) ? f.fx[1] : f.fx[0]) * ((b & 2u) ? f.fy[1] : f.fy[0]);
+    if (DIM == 3) w *= (b & 4u) ? f.fz[1] : f.fz[0];
+    return w;
+}
+// blend of one channel: ((g * fx) * fy) (* fz), corners added left to right (fp_def.py:141-144, 176-183;
+// image_compression.py:95) with individually rounded products and sums
+template <int DIM>
+__device__ __forceinline__ float g1_blend(const float* pc, const GridView& g, const G1Factors& f) {
+    constexpr int K1 = DIM == 2 ? 4 : 8;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < K1; ++q) {
+        const int dx = DIM == 2 ? (q >> 1) : ((q >> 2) & 1), dy = DIM == 2 ? (q & 1) : ((q >> 1) & 1), dz = DIM == 2 ? 0 : (q & 1);
+        const uint32_t b = (f.bits >> (3 * q)) & 7u;
+        float v = pc[g.at(dx, dy, dz)];
+        v = mul_rn(v, (b & 1u) ? f.fx[1] : f.fx[0]);
+        v = mul_rn(v, (b & 2u) ? f.fy[1] : f.fy[0]);
+        if (DIM == 3) v = mul_rn(v, (b & 4u) ? f.fz[1] : f.fz[0]);
+        sum = q == 0 ? v : add_rn(sum, v);
+    }
+    return sum;
+}
+
+// corner offsets of G0 slot group e (the lane-half h fixes dx = h), per layout
+template <class L>
+__device__ __forceinline__ void g0_corner(int e, int h, int& dx, int& dy, int& dz) {
+    dx = h;
+    if (L::DIM == 2) { dy = e; dz = 0; }
+    else if (L::K0 == 8) { dy = (e >> 1) & 1; dz = e & 1; }   // corners 4h + e, bit1 = dy, bit0 = dz
+    else { dy = e; dz = h ^ e; }                              // tetra corners 2h + e: dz = dx ^ dy
+}
+
+// Fills the lane's slots (see Layout<> in nic_device.hpp) for sample (ix,iy,iz) of `crop`.
+template <class L>
+__device__ __forceinline__ void encode_slots(const FusedParams& p, int crop, int ix, int iy, int iz, int h, float (&xs)[L::NSLOT], EncCtx& cx) {
+    constexpr int D = L::DIM;
+    const nic_path_desc& d = p.d;
+    const int e = d.log2_step;
+    Axis ax = axis_coords(p.origins[crop * D + 0] + ix, e);
+    Axis ay = axis_coords(p.origins[crop * D + 1] + iy, e);
+    Axis az;
+    if (D == 3) az = axis_coords(p.origins[crop * D + 2] + iz, e);
+    else { az.i0 = az.i1 = 0; az.t1 = az.k1 = 0.f; }
+    // memory safety: a corner index never leaves the grid, whatever the origins hold
+    const int x0 = clampi(ax.i0, 0, p.g0.nx - 2), y0 = clampi(ay.i0, 0, p.g0.ny - 2), z0 = D == 3 ? clampi(az.i0, 0, p.g0.nz - 2) : 0;
+    const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2), z1 = D == 3 ? clampi(az.i1, 0, p.g1.nz - 2) : 0;
+    cx.off0 = p.g0.at(x0, y0, z0);
+    cx.off1 = p.g1.at(x1, y1, z1);
+    cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = az.k1;
+    constexpr int NG0 = L::K0 / 2 * kC;             // G0 slots per half
+    // --- G0 raw corners
+#pragma unroll
+    for (int s = 0; s < NG0; ++s) {
+        int dx, dy, dz;
+        g0_corner<L>(s / kC, h, dx, dy, dz);
+        xs[s] = p.g0.p[cx.off0 + p.g0.at(dx, dy, dz) + (int64_t)(s % kC) * p.g0.plane];
+    }
+    // --- G1: channels (kC/2)*h + cc
+    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+#pragma unroll
+    for (int cc = 0; cc < kC / 2; ++cc) {
+        const float* pc = p.g1.p + cx.off1 + (int64_t)(kC / 2 * h + cc) * p.g1.plane;
+        xs[NG0 + cc] = g1_blend<D>(pc, p.g1, gf);
+    }
+    // --- remaining slots: PE rows, LOD, the constant one, zero padding.  The channel of a slot is affine
+    // in h, so its kind is known at compile time per half; only PE row / axis are lane-half dependent.
+    float pdiv[kP / 2];
+#pragma unroll
+    for (int i = 0; i < kP / 2; ++i) pdiv[i] = d.pe_div[i];
+#pragma unroll
+    for (int s = NG0 + kC / 2; s < L::NSLOT; ++s) {
+        constexpr int PE0 = (L::K0 + 1) * kC;                 // first PE channel
+        const int ch0 = L::slot_channel(s, 0), ch1 = L::slot_channel(s, 1);
+        const bool pe0 = ch0 >= PE0 && ch0 < L::CIN - 1, pe1 = ch1 >= PE0 && ch1 < L::CIN - 1;
+        float v0 = ch0 == kSlotOne ? 1.0f : (ch0 == L::CIN - 1 ? d.lod_value : 0.f);
+        float v1 = ch1 == kSlotOne ? 1.0f : (ch1 == L::CIN - 1 ? d.lod_value : 0.f);
+        if (pe0 || pe1) {
+            const int pr = (h ? ch1 : ch0) - PE0;             // PE row 0 .. P*D-1 of this lane-half
+            const int a = pr / kP, r = pr - a * kP;
+            const float c = a == 0 ? ax.t1 : (a == 1 ? ay.t1 : az.t1);
+            float v;
+            if (L::PE == NIC_PE_TRIANGULAR) {
+                v = tri_pe_row(c, r, kP);
+            } else {
+                const int k = r >> 1;
+                const float dv = k == 0 ? pdiv[0] : (k == 1 ? pdiv[1] : pdiv[2]);
+                float sv, cv;
+                sincos_cw(__fmul_rn(c, dv), sv, cv);
+                v = (r & 1) ? cv : sv;
+            }
+            if (pe0) v0 = v;
+            if (pe1) v1 = v;
+        }
+        xs[s] = h ? v1 : v0;
+    }
+}
+
+// adds the noise of the slot's reference channel (image_compression.py:250: every real channel)
+template <class L>
+__device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int h, float (&xs)[L::NSLOT]) {
+    if (ns.mode == NIC_NOISE_NONE) return;
+    if (ns.mode == NIC_NOISE_TENSOR) {
+        const float* row = ns.tensor + n_local * L::CIN;
+#pragma unroll
+        for (int s = 0; s < L::NSLOT; ++s) {
+            const int ch = L::slot_channel(s, h);
+            if (ch >= 0) xs[s] += row[ch];
+        }
+        return;
+    }
+    constexpr int NG0 = L::K0 / 2 * kC;              // multiple of 8: the G0 slots of a half are whole blocks
+    static_assert(NG0 % 8 == 0, "G0 slots must cover whole Philox blocks");
+#pragma unroll
+    for (int j = 0; j < NG0 / 8; ++j) {
+        const U4 b = noise_block(ns, sample_global, NG0 / 8 * h + j);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xs[8 * j + t] += noise_from_block(ns, b, t);
+    }
+    constexpr int RB0 = L::K0 * kC / 8;              // first block of the non-G0 channels
+    static_assert((L::CIN - 1) / 8 - RB0 <= 3, "rest channels span at most 4 blocks");
+    U4 rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = noise_block(ns, sample_global, RB0 + j);
+#pragma unroll
+    for (int s = NG0; s < L::NSLOT; ++s) {
+        const int ch = L::slot_channel(s, h);
+        if (ch >= 0) {
+            const int j = (ch >> 3) - RB0;
+            const U4 b = j == 0 ? rb[0] : (j == 1 ? rb[1] : (j == 2 ? rb[2] : rb[3]));
+            xs[s] += noise_from_block(ns, b, ch);
+        }
+    }
+}
+
+// scatter of the grid-slot gradients (index_put_(accumulate=True) of the gathers' backward)
+template <class L, int NT>
+__device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const EncCtx& cx, int h, const f32x16 (&dxacc)[NT]) {
+    constexpr int D = L::DIM;
+    constexpr int NG0 = L::K0 / 2 * kC;
+#pragma unroll
+    for (int s = 0; s < NG0; ++s) {
+        int dx, dy, dz;
+        g0_corner<L>(s / kC, h, dx, dy, dz);
+        atomicAdd(p.g0_grad + cx.off0 + p.g0.at(dx, dy, dz) + (int64_t)(s % kC) * p.g0.plane, dxacc[s >> 4][s & 15]);
+    }
+    constexpr int K1 = D == 2 ? 4 : 8;
+    const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+    float w[K1];
+#pragma unroll
+    for (int q = 0; q < K1; ++q) w[q] = g1_corner_factor<D>(gf, q);
+#pragma unroll
+    for (int cc = 0; cc < kC / 2; ++cc) {
+        const int s = NG0 + cc;
+        const float gsum = dxacc[s >> 4][s & 15];
+        float* pc = p.g1_grad + cx.off1 + (int64_t)(kC / 2 * h + cc) * p.g1.plane;
+#pragma unroll
+        for (int q = 0; q < K1; ++q) {
+            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+            atomicAdd(pc + p.g1.at(dx, dy, dz), gsum * w[q]);
+        }
+    }
+}
+
+// =====================================================================================================
+template <class L, int SRC, int MODE>
+__global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(FusedParams p) {
+    using S = Lds<L>;
+    constexpr bool TRAIN = MODE != MODE_INFER;
+    constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
+    __shared__ __attribute__((aligned(16))) float smem[TRAIN ? S::TOTAL_TRAIN : S::TOTAL_INFER];
+    lds_f* const sm = (lds_f*)smem;
+    lds_f* const W1s = sm + S::OFF_W1;
+    lds_f* const W2s = sm + S::OFF_W2;
+    lds_f* const W3s = sm + S::OFF_W3;
+    lds_f* const B2s = sm + S::OFF_B2;
+    lds_f* const B3s = sm + S::OFF_B3;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+
+    // ---------------- prologue: decoder weights -> LDS (first layer permuted into slot order, bias in the
+    // column of the constant-one slot), scratch zeroed
+    for (int idx = tid; idx < kH * LD1; idx += 256) {
+        const int o = idx / LD1, rho = idx - o * LD1;
+        float v = 0.f;
+        if (rho < S::KPAD) {
+            const int ch = channel_of_rho<L>(rho);
+            if (ch >= 0) v = p.W[0][o * L::CIN + ch];
+            else if (ch == kSlotOne) v = p.b[0][o];
+        }
+        W1s[idx] = v;
+    }
+    for (int idx = tid; idx < kH * LD2; idx += 256) {
+        const int o = idx / LD2, k = idx - o * LD2;
+        W2s[idx] = k < kH ? p.W[1][o * kH + k] : 0.f;
+    }
+    for (int idx = tid; idx < 4 * LD2; idx += 256) {
+        const int o = idx / LD2, k = idx - o * LD2;
+        W3s[idx] = (o < 3 && k < kH) ? p.W[2][o * kH + k] : 0.f;
+    }
+    if (tid < kH) B2s[tid] = p.b[1][tid];
+    if (tid < 16) B3s[tid] = tid < 3 ? p.b[2][tid] : 0.f;
+    if (TRAIN)
+        for (int idx = tid; idx < 4 * S::SCR_PER_WAVE; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
+    __syncthreads();
+
+    lds_f* const SA = sm + S::OFF_SCR + (TRAIN ? wave * S::SCR_PER_WAVE : 0);
+    lds_f* const SB = SA + 64 * LDT;
+
+    // ---------------- launch-lifetime accumulators (training)
+    f32x16 accW1[2][KT], accW2[2][2];
+    float accW3[3] = {0.f, 0.f, 0.f};     // dW3[c][k = lane]
+    float accB2 = 0.f;                    // db2[o = lane]
+    float accB3[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
+    if (TRAIN) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int b = 0; b < KT; ++b) accW1[a][b] = f32x16(0.f);
+            accW2[a][0] = accW2[a][1] = f32x16(0.f);
+        }
+    }
+
+    // ---------------- XCD-aware persistent tile walk
+    const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
+    const int64_t chunk = (p.n_tiles + 7) >> 3;
+    const int64_t t_begin = xcd * chunk;
+    const int64_t t_end = t_begin + chunk < p.n_tiles ? t_begin + chunk : p.n_tiles;
+    const int lstride = nb8 * 4;
+
+    for (int64_t tile = t_begin + (blockIdx.x >> 3) * 4 + wave; tile < t_end; tile += lstride) {
+        // ---------- per-lane LDS bases (every access below is base[compile-time constant])
+        lds_cf* const w1_row = opaque(W1s + pl * LD1 + 4 * h);      // A rows of layer 1 (b128 along k)
+        lds_cf* const w2_row = opaque(W2s + pl * LD2 + 4 * h);
+        lds_cf* const w3_row = opaque(W3s + 4 * h);
+        lds_cf* const b2_row = opaque(B2s + 4 * h);
+        lds_cf* const w3_col = opaque(W3s + h * LD2 + pl);          // A columns (b32 along the out index)
+        lds_cf* const w2_col = opaque(W2s + 4 * h * LD2 + pl);
+        lds_cf* const w1_col = opaque(W1s + 4 * h * LD1 + pl);
+        lds_f* const sa_st = opaque(SA + 4 * h * LDT + pl);              // transposed stores: row ROWC(r)+4h, col pl
+        lds_f* const sb_st = opaque(SB + 4 * h * LDT + pl);
+        lds_cf* const sa_rd = opaque(SA + pl * LDT + 16 * h);       // operand reads: row pl, samples 16h..
+        lds_cf* const sb_rd = opaque(SB + pl * LDT + 16 * h);
+        lds_cf* const sa_lane = opaque(SA + lane * LDT);            // row passes: lane walks row `lane`
+        lds_cf* const sb_lane = opaque(SB + lane * LDT);
+        lds_cf* const sa_bc = opaque(SA);                           // broadcast reads of rows 0..2
+
+        // ---------- which sample does this lane own
+        bool valid;
+        int64_t n;          // sample index inside this launch
+        int crop = 0, ix = 0, iy = 0, iz = 0;
+        if (SRC == SRC_ENCODE) {
+            crop = (int)(tile / p.tiles_per_crop);
+            int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
+            int lx, ly, lz = 0;
+            if (L::DIM == 2) {
+                lx = pl / L::TY; ly = pl % L::TY;
+                const int ty = tt % p.tiles_y, tx = tt / p.tiles_y;
+                ix = tx * L::TX + lx; iy = ty * L::TY + ly;
+            } else {
+                lx = pl / (L::TY * L::TZ); ly = (pl / L::TZ) % L::TY; lz = pl % L::TZ;
+                const int tz = tt % p.tiles_z; tt /= p.tiles_z;
+                const int ty = tt % p.tiles_y, tx = tt / p.tiles_y;
+                ix = tx * L::TX + lx; iy = ty * L::TY + ly; iz = tz * L::TZ + lz;
+            }
+            const int ez = L::DIM == 3 ? p.d.extent[2] : 1;
+            valid = ix < p.d.extent[0] && iy < p.d.extent[1] && iz < ez;
+            ix = ix < p.d.extent[0] ? ix : p.d.extent[0] - 1;
+            iy = iy < p.d.extent[1] ? iy : p.d.extent[1] - 1;
+            iz = iz < ez ? iz : ez - 1;
+            n = (int64_t)crop * p.n_per_crop + ((int64_t)ix * p.d.extent[1] + iy) * ez + iz;
+        } else {
+            n = tile * 32 + pl;
+            valid = n < p.n_total;
+            n = valid ? n : p.n_total - 1;
+        }
+
+        // ---------- input slots
+        float xs[L::NSLOT];
+        EncCtx cx;
+        if (SRC == SRC_ENCODE) {
+            encode_slots<L>(p, crop, ix, iy, iz, h, xs, cx);
+            add_noise<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, h, xs);
+        } else {
+            const float* row = p.x + n * L::CIN;
+#pragma unroll
+            for (int s = 0; s < L::NSLOT; ++s) {
+                const int ch = L::slot_channel(s, h);
+                xs[s] = ch >= 0 ? row[ch] : (ch == kSlotOne ? 1.0f : 0.f);
+            }
+        }
+
+        // ---------- layer 1: Z1[o][s] = sum_rho W1p[o][rho] X[rho][s]   (bias rides on the constant-one slot)
+        f32x16 a1[2], d1[2];
+        {
+            f32x16 z[2] = {f32x16(0.f), f32x16(0.f)};
+#pragma unroll
+            for (int s4 = 0; s4 < L::NSLOT / 4; ++s4) {
+                const int sig = 4 * s4;
+                const int col = 32 * (sig >> 4) + 8 * ((sig & 15) >> 2);
+#pragma unroll
+                for (int to = 0; to < 2; ++to) {
+                    const f32x4 a = ld4(&w1_row[32 * to * LD1 + col]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[to] = mfma32(a[j], xs[sig + j], z[to]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a, d;
+                    if (TRAIN) gelu_and_grad(z[to][r], a, d);
+                    else { a = gelu_only(z[to][r]); d = 0.f; }
+                    a1[to][r] = a;
+                    d1[to][r] = d;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- layer 2
+        f32x16 a2[2], d2[2];
+        {
+            f32x16 z[2];
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 bb = ld4(&b2_row[32 * to + 8 * r4]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[to][4 * r4 + j] = bb[j];
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int col = 32 * t + 8 * r4;
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        const f32x4 a = ld4(&w2_row[32 * to * LD2 + col]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[to] = mfma32(a[j], a1[t][4 * r4 + j], z[to]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a, d;
+                    if (TRAIN) gelu_and_grad(z[to][r], a, d);
+                    else { a = gelu_only(z[to][r]); d = 0.f; }
+                    a2[to][r] = a;
+                    d2[to][r] = d;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- layer 3: only 3 outputs - a 32-row MFMA tile would be 90 % padding, so each lane dots its
+        // 32 hidden values with the matching W3 columns (broadcast LDS reads) and the two halves are added
+        float yv[3];
+        {
+            float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int col = 32 * t + 8 * r4;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const f32x4 w = ld4(&w3_row[c * LD2 + col]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) part[c] = fmaf(w[j], a2[t][4 * r4 + j], part[c]);
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(part[c] + __shfl_xor(part[c], 32) + B3s[c]);
+        }
+        if (p.y != nullptr && valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+        }
+        if (!TRAIN) continue;
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dZ3 (lane-half 0 owns the sample's 3 outputs)
+        float dz3[3];
+        {
+            const bool own = valid && h == 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float g;
+                if (MODE == MODE_TRAIN_MSE) {
+                    const float diff = own ? yv[c] - p.target[n * 3 + c] : 0.f;
+                    accLoss += diff * diff;
+                    g = p.grad_scale * diff;
+                } else {
+                    g = own ? p.dy[n * 3 + c] : 0.f;
+                }
+                dz3[c] = g * yv[c] * (1.0f - yv[c]);
+                accB3[c] += dz3[c];
+            }
+        }
+        // ---------- dW3[c][k] += sum_s dZ3[c][s] A2[k][s]: lane k walks row k of the transposed A2 image
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sa_st[c * LDT] = dz3[c];          // h == 0: sa_st = SA + pl
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sb_st[(32 * t + ROWC(r)) * LDT] = a2[t][r];
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 av = ld4(&sb_lane[4 * g]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 zv = ld4(&sa_bc[c * LDT + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accW3[c] = fmaf(zv[j], av[j], accW3[c]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dA2 = W3^T dZ3 (K = 3, padded to 4), dZ2 = dA2 * gelu'(Z2)
+        f32x16 dz2[2];
+        {
+            const float s1 = __shfl(dz3[1], pl);
+            const float b0 = h ? s1 : dz3[0];
+            const float b1 = h ? 0.f : dz3[2];
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk) {
+                f32x16 acc = f32x16(0.f);
+                acc = mfma32(w3_col[32 * tk], b0, acc);
+                acc = mfma32(w3_col[2 * LD2 + 32 * tk], b1, acc);
+                dz2[tk] = acc * d2[tk];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dW2[o][k] += sum_s dZ2[o][s] A1[k][s]
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sa_st[(32 * t + ROWC(r)) * LDT] = dz2[t][r];
+                sb_st[(32 * t + ROWC(r)) * LDT] = a1[t][r];
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                                  // db2[o = lane] += sum_s dZ2[o][s]
+            const f32x4 zv = ld4(&sa_lane[4 * g]);
+            accB2 += (zv[0] + zv[1]) + (zv[2] + zv[3]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = ld4(&sa_rd[32 * t * LDT + 4 * g]);
+                b[t] = ld4(&sb_rd[32 * t * LDT + 4 * g]);
+            }
+#pragma unroll
+            for (int to = 0; to < 2; ++to)
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accW2[to][tk] = mfma32(a[to][j], b[tk][j], accW2[to][tk]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dA1 = W2^T dZ2, dZ1 = dA1 * gelu'(Z1)
+        f32x16 dz1[2];
+        {
+            f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = 32 * t + ROWC(r);
+#pragma unroll
+                    for (int tk = 0; tk < 2; ++tk) acc[tk] = mfma32(w2_col[o * LD2 + 32 * tk], dz2[t][r], acc[tk]);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            dz1[0] = acc[0] * d1[0];
+            dz1[1] = acc[1] * d1[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dW1[o][rho] += sum_s dZ1[o][s] X[rho][s]   (X staged two 32-row tiles at a time)
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa_st[(32 * t + ROWC(r)) * LDT] = dz1[t][r];
+#pragma unroll
+        for (int c2 = 0; c2 < (KT + 1) / 2; ++c2) {
+            if (c2 > 0) wave_lds_fence();
+#pragma unroll
+            for (int s = 32 * c2; s < 32 * c2 + 32 && s < L::NSLOT; ++s) sb_st[(32 * ((s >> 4) & 1) + ROWC(s & 15)) * LDT] = xs[s];
+            wave_lds_fence();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a[2];
+#pragma unroll
+                for (int to = 0; to < 2; ++to) a[to] = ld4(&sa_rd[32 * to * LDT + 4 * g]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (2 * c2 + tt < KT) {
+                        const f32x4 b = ld4(&sb_rd[32 * tt * LDT + 4 * g]);
+#pragma unroll
+                        for (int to = 0; to < 2; ++to)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) accW1[to][2 * c2 + tt] = mfma32(a[to][j], b[j], accW1[to][2 * c2 + tt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------- dX = W1p^T dZ1 for the slots that need it
+        constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : KT;
+        if (SRC == SRC_ENCODE || p.dx != nullptr) {
+            f32x16 dxacc[NGT];
+#pragma unroll
+            for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = 32 * t + ROWC(r);
+#pragma unroll
+                    for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma32(w1_col[o * LD1 + 32 * tg], dz1[t][r], dxacc[tg]);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            if (SRC == SRC_ENCODE) {
+                if (valid) scatter_grid_grads<L, NGT>(p, cx, h, dxacc);
+            } else if (valid) {
+                float* row = p.dx + n * L::CIN;
+#pragma unroll
+                for (int s = 0; s < L::NSLOT; ++s) {
+                    const int ch = L::slot_channel(s, h);
+                    if (ch >= 0) row[ch] = dxacc[s >> 4][s & 15];
+                }
+            }
+        }
+    }  // tile loop
+
+    if (!TRAIN) return;
+    // ---------------- flush the accumulators of this wave: [NACC][16 regs][64 lanes], then db2[64], db3[3], loss
+    float* rec = p.partials + ((int64_t)blockIdx.x * 4 + wave) * S::REC;
+    int a = 0;
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int tk = 0; tk < KT; ++tk, ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rec[(a * 16 + r) * 64 + lane] = accW1[to][tk][r];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk, ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rec[(a * 16 + r) * 64 + lane] = accW2[to][tk][r];
+    float* tail = rec + S::NACC * 1024;
+    tail[lane] = accB2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tail[64 + 64 * c + lane] = accW3[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = c < 3 ? accB3[c] : accLoss;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) tail[256 + c] = v;
+    }
+}
+
+// =====================================================================================================
+// Fixed-order reduction of the per-wave records into the decoder gradients (nn.Linear layouts) and loss.
+template <class L>
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale) {
+    using S = Lds<L>;
+    constexpr int KT = S::KT;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= S::NACC * 1024 + S::TAIL) return;
+    float acc = 0.f;
+    for (int w = 0; w < n_waves; ++w) acc += partials[(int64_t)w * S::REC + gid];
+    if (gid < S::NACC * 1024) {
+        const int a = gid >> 10, r = (gid >> 6) & 15, lane = gid & 63;
+        const int row = ROW(r, lane >> 5), col = lane & 31;
+        if (a < 2 * KT) {                                       // dW1 tile (to, tk)
+            const int to = a / KT, tk = a % KT;
+            const int o = 32 * to + row, rho = 32 * tk + col;
+            const int ch = rho < S::KPAD ? channel_of_rho<L>(rho) : kSlotZero;
+            if (ch >= 0) { if (g.w[0]) g.w[0][o * L::CIN + ch] = acc; }
+            else if (ch == kSlotOne) { if (g.b[0]) g.b[0][o] = acc; }
+        } else {                                                // dW2 tile (to, tk)
+            const int q = a - 2 * KT;
+            if (g.w[1]) g.w[1][(32 * (q >> 1) + row) * kH + 32 * (q & 1) + col] = acc;
+        }
+    } else {
+        const int t = gid - S::NACC * 1024;
+        if (t < 64) { if (g.b[1]) g.b[1][t] = acc; }
+        else if (t < 256) { if (g.w[2]) g.w[2][t - 64] = acc; }            // [3][64] row-major
+        else if (t < 259) { if (g.b[2]) g.b[2][t - 256] = acc; }
+        else if (loss) *loss = acc * loss_scale;
+    }
+}
+
+}  // namespace nic

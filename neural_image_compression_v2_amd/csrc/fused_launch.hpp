@@ -1,0 +1,48 @@
+// Host-side launchers of the fused kernels; one translation unit per layout (fused_m1/m3/m4.hip) so the
+// three big template instantiation sets compile in parallel.
+#pragma once
+#include "fused_kernel.hpp"
+
+namespace nic {
+
+struct FusedInfo {
+    int nacc, rec, tx, ty, tz, cin;
+};
+
+template <int METHOD>
+FusedInfo fused_info();
+template <int METHOD>
+int launch_fused(int src, int mode, const FusedParams& p, int grid, hipStream_t s);
+template <int METHOD>
+int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+
+#define NIC_INSTANTIATE_LAYOUT(METHOD)                                                                                   \
+    template <>                                                                                                          \
+    FusedInfo fused_info<METHOD>() {                                                                                     \
+        using L = Layout<METHOD>;                                                                                        \
+        return FusedInfo{Lds<L>::NACC, Lds<L>::REC, L::TX, L::TY, L::TZ, L::CIN};                                        \
+    }                                                                                                                    \
+    template <>                                                                                                          \
+    int launch_fused<METHOD>(int src, int mode, const FusedParams& p, int grid, hipStream_t s) {                         \
+        using L = Layout<METHOD>;                                                                                        \
+        const dim3 g(grid), b(256);                                                                                      \
+        if (src == SRC_ENCODE) {                                                                                         \
+            if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);        \
+            else if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE>), g, b, 0, s, p); \
+            else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY>), g, b, 0, s, p);                        \
+        } else {                                                                                                         \
+            if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_MEMORY, MODE_INFER>), g, b, 0, s, p);        \
+            else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_kernel<L, SRC_MEMORY, MODE_TRAIN_DY>), g, b, 0, s, p); \
+            else return NIC_E_UNSUPPORTED;                                                                               \
+        }                                                                                                                \
+        return (int)hipGetLastError();                                                                                   \
+    }                                                                                                                    \
+    template <>                                                                                                          \
+    int launch_reduce<METHOD>(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
+        using L = Layout<METHOD>;                                                                                        \
+        const int n = Lds<L>::NACC * 1024 + Lds<L>::TAIL;                                                                          \
+        hipLaunchKernelGGL((reduce_partials_kernel<L>), dim3((n + 255) / 256), dim3(256), 0, s, partials, n_waves, g, loss, loss_scale); \
+        return (int)hipGetLastError();                                                                                   \
+    }
+
+}  // namespace nic

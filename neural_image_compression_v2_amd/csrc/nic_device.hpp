@@ -1,0 +1,256 @@
+// Shared device code for the gfx950 kernels: per-axis sample coordinates, positional encodings, GELU,
+// Philox noise and the slot layouts that map decoder-input channels onto MFMA operand registers.
+// Reference citations are relative to /root/reference/Projects.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nicv2_hip.h"
+
+namespace nic {
+
+constexpr int kC = 12;   // FEATURE_PYRAMID_CHANNELS the MFMA kernels are built for (var2.py:68)
+constexpr int kP = 6;    // PE_CHANNELS (var2.py:69)
+constexpr int kH = 64;   // HIDDEN_LAYER_CHANNELS (var2.py:72)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// Sample coordinates along one axis (fp_def.py:116-123, 137-138).  q = range + origin is an integer;
+// step = 2^e, so t0 = q*2^e, i0 = floor(t0), t1 = t0/2, i1 = floor(t1), k1 = t1 - i1 are all exact.
+// ---------------------------------------------------------------------------------------------------
+struct Axis {
+    int i0, i1;
+    float t1, k1;
+};
+
+__device__ __forceinline__ Axis axis_coords(int q, int e) {
+    Axis a;
+    a.i0 = e < 0 ? (q >> (-e)) : (q << e);
+    const int e1 = e - 1;
+    a.i1 = e1 < 0 ? (q >> (-e1)) : (q << e1);
+    a.t1 = ldexpf((float)q, e1);
+    a.k1 = a.t1 - (float)a.i1;
+    return a;
+}
+
+// products / sums that must not be contracted into FMAs: the reference evaluates
+// ((g * wx) * wy) (* wz) and adds the corners left to right in fp32 (fp_def.py:141-144, 176-183;
+// image_compression.py:95), and the encode is held to bit-exactness against it.
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+// ---------------------------------------------------------------------------------------------------
+// Positional encodings
+// ---------------------------------------------------------------------------------------------------
+// tri(x, o) = 2*|((x - o) mod 2) - 1| - 1 with floor-mod (utils.py:226-227)
+__device__ __forceinline__ float tri_wave(float x, float o) {
+    const float v = x - o;
+    const float m = v - 2.0f * floorf(v * 0.5f);
+    return 2.0f * fabsf(m - 1.0f) - 1.0f;
+}
+
+// row r (0..P-1) of the triangular PE block of one dimension (utils.py:211-223):
+// row P-1 is zero, row P-2 = tri(c, 0), then pairs (tri(c/2^o, 0), tri(c/2^o, .5)) going up.
+__device__ __forceinline__ float tri_pe_row(float c, int r, int P) {
+    const int u = P - 1 - r;            // u = 2*octave + i, offsets (0.5, 0.0) for i = (0, 1)
+    const int octave = u >> 1;
+    const float off = (u & 1) ? 0.0f : 0.5f;
+    const float v = tri_wave(ldexpf(c, -octave), off);
+    return u <= 0 ? 0.0f : v;           // octave 0 / offset 0.5 is skipped -> stays zero
+}
+
+// sin and cos by 3-term Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials (branch-free apart
+// from the quadrant select; abs error < 2e-7 for |x| < 2^15, far inside the arguments PE sees: c <= a few
+// thousand).  The library sinf/cosf carry a Payne-Hanek slow path that bloats the fused kernel.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+    const float kf = rintf(x * 0.63661977236758134308f);            // x * 2/pi
+    float r = fmaf(kf, -1.57079601287841796875f, x);                 // pi/2 split in 3 parts
+    r = fmaf(kf, -3.1391647326017846353e-07f, r);
+    r = fmaf(kf, -5.3903025299577647655e-15f, r);
+    const float r2 = r * r;
+    float sp = fmaf(r2, 2.6083159809786593541503e-06f, -0.0001981069071916863322258f);
+    sp = fmaf(sp, r2, 0.00833307858556509017944336f);
+    sp = fmaf(sp, r2, -0.166666597127914428710938f);
+    const float sr = fmaf(r * r2, sp, r);
+    float cp = fmaf(r2, -2.7181184236542321741581e-07f, 2.4799044695100747048855e-05f);
+    cp = fmaf(cp, r2, -0.00138887774664908647537231f);
+    cp = fmaf(cp, r2, 0.0416666641831398010253906f);
+    cp = fmaf(cp, r2, -0.5f);
+    const float cr = fmaf(cp, r2, 1.0f);
+    const int k = (int)kf;
+    const float ss = (k & 1) ? cr : sr;
+    const float cc = (k & 1) ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+}
+// row r of the sinusoidal block: even -> sin(c * div[r/2]), odd -> cos (utils.py:198-208)
+__device__ __forceinline__ float sin_pe_row(float c, int r, const float* div) {
+    const float a = __fmul_rn(c, div[r >> 1]);
+    float sv, cv;
+    sincos_cw(a, sv, cv);
+    return (r & 1) ? cv : sv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GELU (exact erf form, nn.GELU() default, image_compression.py:59) and its derivative
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gelu_and_grad(float z, float& a, float& d) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    a = z * cdf;
+    d = cdf + z * (0.39894228040143267794f * __expf(-0.5f * z * z));
+}
+__device__ __forceinline__ float gelu_only(float z) {
+    return z * (0.5f * (1.0f + erff(z * 0.70710678118654752440f)));
+}
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// ---------------------------------------------------------------------------------------------------
+// Philox-4x32-10; noise definition restated in oracle/nic_oracle.py::philox_noise
+// ---------------------------------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+struct NoiseSrc {
+    int mode;               // NIC_NOISE_*
+    const float* tensor;    // [N, Cin] when mode == TENSOR
+    uint32_t k0, k1, off_lo, off_hi;
+    float scale;            // 2^-num_bits
+};
+
+// one Philox block = 8 channels (4 words x 2 halves) of one sample
+__device__ __forceinline__ U4 noise_block(const NoiseSrc& ns, uint64_t sample, int blk) {
+    U4 c{(uint32_t)sample, (uint32_t)blk + ((uint32_t)(sample >> 32) << 8), ns.off_lo, ns.off_hi};
+    return philox4x32_10(c, ns.k0, ns.k1);
+}
+__device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& b, int ch) {
+    const int w = (ch >> 1) & 3;
+    const uint32_t word = w == 0 ? b.x : (w == 1 ? b.y : (w == 2 ? b.z : b.w));
+    const uint32_t u16 = (ch & 1) ? (word >> 16) : (word & 0xFFFFu);
+    return (((float)u16 + 0.5f) * (1.0f / 65536.0f) - 0.5f) * ns.scale;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Grid addressing.  Tensor [C, (Z,) Y, X] (fp_def.py:54,76), per-axis node counts in (x, y, z) order.
+// ---------------------------------------------------------------------------------------------------
+struct GridView {
+    const float* p;
+    int nx, ny, nz;      // nodes per axis
+    int64_t plane;       // elements per channel = nx*ny*nz
+    __device__ __forceinline__ int64_t at(int x, int y, int z) const { return ((int64_t)z * ny + y) * nx + x; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Slot layouts for the MFMA kernels.
+//
+// A wave works on 32 samples; lane l = (p = l & 31, h = l >> 5) belongs to sample p and owns "slots"
+// sigma = 0 .. NSLOT-1 of that sample's padded input vector.  Slot sigma of half h is row
+//     rho(sigma, h) = 32*(sigma >> 4) + ROW(sigma & 15, h),   ROW(r, h) = (r & 3) + 8*(r >> 2) + 4*h
+// of the internal [KPAD, 32] input matrix - exactly the row a 32x32 MFMA accumulator register r of
+// lane-half h holds - so (a) the slot values are the B operand of the first layer with no data
+// movement (k-step (sigma, {h=0,1})) and (b) the input gradient comes out of the last backward
+// product in the registers of the lane that knows the slot's grid address.  The first NGRID slots are
+// the gathered grid features (they need gradients), the rest are PE / LOD / the constant 1 that
+// carries the first bias / zero padding.  slot_channel() gives the reference's decoder-input channel
+// of a slot (image_compression.py:94-96 channel order), -1 for zero padding, -2 for the constant 1.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSlotZero = -1;
+constexpr int kSlotOne = -2;
+
+__host__ __device__ constexpr int ROW(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__host__ __device__ constexpr int rho_of(int sigma, int h) { return 32 * (sigma >> 4) + ROW(sigma & 15, h); }
+
+template <int METHOD>
+struct Layout;
+
+// 2D (COMPRESSION_METHOD 1): Cin = 4*12 + 12 + 2*6 + 1 = 73
+struct Layout2D {
+    static constexpr int DIM = 2, K0 = 4, K1 = 4, CIN = 73;
+    static constexpr int NSLOT = 40;   // 16 + 16 + 8  -> KPAD = 80
+    static constexpr int NGRID = 30;   // 24 G0 (2 corners x 12 ch) + 6 G1 channels per half
+    static constexpr int TX = 4, TY = 8, TZ = 1;   // wave tile of 32 samples
+    __host__ __device__ static constexpr int slot_channel(int s, int h) {
+        if (s < 24) return 24 * h + s;                  // G0 corner 2h + s/12, channel s%12
+        if (s < 30) return 48 + 6 * h + (s - 24);       // G1 channel 6h + ..
+        if (s < 32) return kSlotZero;
+        if (s < 38) return 60 + 6 * h + (s - 32);       // PE of dimension h
+        if (s == 38) return h == 0 ? 72 : kSlotOne;     // LOD | bias carrier
+        return kSlotZero;
+    }
+};
+template <>
+struct Layout<1> : Layout2D {                           // TF_USE_TRI_PE = True (var2.py:81)
+    static constexpr int PE = NIC_PE_TRIANGULAR;
+};
+template <>
+struct Layout<2> : Layout2D {                           // TF_USE_TRI_PE = False
+    static constexpr int PE = NIC_PE_SINUSOIDAL;
+};
+// 3D method 3: Cin = 8*12 + 12 + 3*6 + 1 = 127
+template <>
+struct Layout<3> {
+    static constexpr int DIM = 3, K0 = 8, K1 = 8, CIN = 127;
+    static constexpr int PE = NIC_PE_TRIANGULAR;        // fp_def.py:169
+    static constexpr int NSLOT = 64;   // KPAD = 128
+    static constexpr int NGRID = 54;   // 48 G0 (4 corners) + 6 G1
+    static constexpr int TX = 2, TY = 4, TZ = 4;
+    __host__ __device__ static constexpr int slot_channel(int s, int h) {
+        if (s < 48) return 48 * h + s;                  // G0 corner 4h + s/12
+        if (s < 54) return 96 + 6 * h + (s - 48);
+        if (s < 63) return 108 + 9 * h + (s - 54);      // PE rows 9h .. 9h+8
+        return h == 0 ? 126 : kSlotOne;
+    }
+};
+// 3D method 4 (tetrahedral G0): Cin = 4*12 + 12 + 18 + 1 = 79
+template <>
+struct Layout<4> {
+    static constexpr int DIM = 3, K0 = 4, K1 = 8, CIN = 79;
+    static constexpr int PE = NIC_PE_SINUSOIDAL;        // fp_def.py:208
+    static constexpr int NSLOT = 44;   // 16 + 16 + 12 -> KPAD = 88
+    static constexpr int NGRID = 30;
+    static constexpr int TX = 2, TY = 4, TZ = 4;
+    __host__ __device__ static constexpr int slot_channel(int s, int h) {
+        if (s < 24) return 24 * h + s;                  // G0 corner 2h + s/12
+        if (s < 30) return 48 + 6 * h + (s - 24);
+        if (s < 32) return kSlotZero;
+        if (s < 41) return 60 + 9 * h + (s - 32);
+        if (s == 41) return h == 0 ? 78 : kSlotOne;
+        return kSlotZero;
+    }
+};
+
+// inverse map: internal row rho -> decoder-input channel (or kSlotZero / kSlotOne)
+template <class L>
+__host__ __device__ constexpr int channel_of_rho(int rho) {
+    const int t = rho >> 5, rr = rho & 31;
+    const int h = (rr >> 2) & 1;
+    const int reg = (rr & 3) + 4 * (rr >> 3);
+    const int sigma = 16 * t + reg;
+    return sigma < L::NSLOT ? L::slot_channel(sigma, h) : kSlotZero;
+}
+
+// corner offsets (dx, dy, dz) of the reference's corner numbering
+// 2D  (fp_def.py:82-85):   0:(0,0) 1:(0,1) 2:(1,0) 3:(1,1)            -> dx = q>>1, dy = q&1
+// 3D  (fp_def.py:96-103):  q bit0 = dz, bit1 = dy, bit2 = dx
+// tetra (fp_def.py:108-111): 0:(0,0,0) 1:(0,1,1) 2:(1,0,1) 3:(1,1,0)  -> dx = q>>1, dy = q&1, dz = dx^dy
+// Q1 (fp_def.py:176-183): factor bits (bx,by,bz) the reference multiplies G1 corner q with (1 -> k, 0 -> 1-k):
+//   q: 0:(0,0,0) 1:(0,0,1) 2:(0,1,0) 3:(1,0,0) 4:(1,1,0) 5:(1,0,1) 6:(0,1,1) 7:(1,1,1)
+__device__ __forceinline__ int g1_ref_weight_bits(int q) {
+    // packed as bx | by<<1 | bz<<2, indexed by q
+    constexpr uint32_t tbl = (0u << 0) | (4u << 3) | (2u << 6) | (1u << 9) | (3u << 12) | (5u << 15) | (6u << 18) | (7u << 21);
+    return (tbl >> (3 * q)) & 7;
+}
+
+}  // namespace nic

@@ -1,0 +1,473 @@
+// Element-wise / gather kernels of the path that are not matrix shaped: the reference-layout encode
+// (one thread per sample), positional encodings on explicit coordinates, the quantisers and uint8
+// codec, PSNR and the fused Adam + clamp step.  All HBM-bound streaming kernels: coalesced accesses,
+// grid-stride loops capped at 2048 blocks.
+#include "nic_device.hpp"
+#include <math.h>
+
+namespace nic {
+
+// ---------------------------------------------------------------------------------------------------
+// encode, reference channel order.  SPLIT = false: out[n, Cin] rows (create_decoder_input_*,
+// image_compression.py:71-167).  SPLIT = true: out[row, n] with the G1 corners kept separate
+// (create_g0_g1*, fp_def.py:115-223).
+// ---------------------------------------------------------------------------------------------------
+struct EncodeParams {
+    nic_path_desc d;
+    GridView g0, g1;
+    const int32_t* origins;
+    float* out;
+    int cin;
+    int64_t n_per_crop, n_total;
+};
+
+// memory safety: a corner index never leaves the grid (same clamp as the fused kernels)
+__device__ __forceinline__ int cl(int i, int nodes) { return i < 0 ? 0 : (i > nodes - 2 ? nodes - 2 : i); }
+
+template <int DIM, bool SPLIT>
+__global__ void __launch_bounds__(256) encode_kernel(EncodeParams p) {
+    const nic_path_desc& d = p.d;
+    const int C = d.channels, P = d.pe_channels;
+    const int K0 = (DIM == 2 || d.method == 4) ? 4 : 8;
+    const int K1 = DIM == 2 ? 4 : 8;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < p.n_total; n += (int64_t)gridDim.x * blockDim.x) {
+        const int crop = (int)(n / p.n_per_crop);
+        int64_t r = n - (int64_t)crop * p.n_per_crop;
+        int idx[3] = {0, 0, 0};
+        if (DIM == 3) { idx[2] = (int)(r % d.extent[2]); r /= d.extent[2]; }
+        idx[1] = (int)(r % d.extent[1]);
+        idx[0] = (int)(r / d.extent[1]);
+        Axis ax[3];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) ax[a] = axis_coords(p.origins[crop * DIM + a] + idx[a], d.log2_step);
+        if (DIM == 2) { ax[2].i0 = ax[2].i1 = 0; ax[2].t1 = ax[2].k1 = 0.f; }
+
+        float* o = SPLIT ? p.out + (n - (int64_t)crop * p.n_per_crop) : p.out + n * p.cin;
+        const int64_t os = SPLIT ? p.n_per_crop : 1;      // stride between consecutive channels
+        int row = 0;
+        // --- G0: raw corners, corner-major then channel
+        for (int q = 0; q < K0; ++q) {
+            int dx, dy, dz;
+            if (DIM == 2) { dx = q >> 1; dy = q & 1; dz = 0; }
+            else if (d.method == 4) { dx = q >> 1; dy = q & 1; dz = dx ^ dy; }
+            else { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+            const float* base = p.g0.p + p.g0.at(cl(ax[0].i0, p.g0.nx) + dx, cl(ax[1].i0, p.g0.ny) + dy, DIM == 3 ? cl(ax[2].i0, p.g0.nz) + dz : 0);
+            for (int c = 0; c < C; ++c) o[(row++) * os] = base[c * p.g0.plane];
+        }
+        // --- G1: weighted corners
+        for (int c = 0; c < C; ++c) {
+            float sum = 0.f;
+            for (int q = 0; q < K1; ++q) {
+                int dx, dy, dz;
+                if (DIM == 2) { dx = q >> 1; dy = q & 1; dz = 0; }
+                else { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+                float v = p.g1.p[c * p.g1.plane + p.g1.at(cl(ax[0].i1, p.g1.nx) + dx, cl(ax[1].i1, p.g1.ny) + dy, DIM == 3 ? cl(ax[2].i1, p.g1.nz) + dz : 0)];
+                if (d.g1_weight_mode != NIC_G1_UNWEIGHTED) {
+                    int bits = dx | (dy << 1) | (dz << 2);
+                    if (DIM == 3 && d.g1_weight_mode == NIC_G1_REFERENCE) bits = g1_ref_weight_bits(q);
+                    v = mul_rn(v, (bits & 1) ? ax[0].k1 : 1.0f - ax[0].k1);
+                    v = mul_rn(v, (bits & 2) ? ax[1].k1 : 1.0f - ax[1].k1);
+                    if (DIM == 3) v = mul_rn(v, (bits & 4) ? ax[2].k1 : 1.0f - ax[2].k1);
+                }
+                if (SPLIT) o[(int64_t)(K0 * C + q * C + c) * os] = v;
+                else sum = q == 0 ? v : add_rn(sum, v);
+            }
+            if (!SPLIT) o[(int64_t)(K0 * C + c) * os] = sum;
+        }
+        row = SPLIT ? (K0 + K1) * C : (K0 + 1) * C;
+        // --- PE on the G1-cell coordinate t1, dimension-major
+        for (int a = 0; a < DIM; ++a)
+            for (int r2 = 0; r2 < P; ++r2)
+                o[(int64_t)(row++) * os] = d.pe_mode == NIC_PE_TRIANGULAR ? tri_pe_row(ax[a].t1, r2, P) : sin_pe_row(ax[a].t1, r2, d.pe_div);
+        // --- LOD
+        if (!SPLIT) o[(int64_t)row * os] = d.lod_value;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward of encode_kernel<DIM,false>: scatter-add of dx[n, Cin] into the two grid gradients
+struct EncodeBwdParams {
+    nic_path_desc d;
+    GridView g0, g1;          // .p unused; geometry only
+    const int32_t* origins;
+    const float* dx;
+    float* g0_grad;
+    float* g1_grad;
+    int cin;
+    int64_t n_per_crop, n_total;
+};
+
+template <int DIM>
+__global__ void __launch_bounds__(256) encode_backward_kernel(EncodeBwdParams p) {
+    const nic_path_desc& d = p.d;
+    const int C = d.channels;
+    const int K0 = (DIM == 2 || d.method == 4) ? 4 : 8;
+    const int K1 = DIM == 2 ? 4 : 8;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < p.n_total; n += (int64_t)gridDim.x * blockDim.x) {
+        const int crop = (int)(n / p.n_per_crop);
+        int64_t r = n - (int64_t)crop * p.n_per_crop;
+        int idx[3] = {0, 0, 0};
+        if (DIM == 3) { idx[2] = (int)(r % d.extent[2]); r /= d.extent[2]; }
+        idx[1] = (int)(r % d.extent[1]);
+        idx[0] = (int)(r / d.extent[1]);
+        Axis ax[3];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) ax[a] = axis_coords(p.origins[crop * DIM + a] + idx[a], d.log2_step);
+        if (DIM == 2) { ax[2].i0 = ax[2].i1 = 0; ax[2].t1 = ax[2].k1 = 0.f; }
+        const float* row = p.dx + n * p.cin;
+        for (int q = 0; q < K0; ++q) {
+            int dx, dy, dz;
+            if (DIM == 2) { dx = q >> 1; dy = q & 1; dz = 0; }
+            else if (d.method == 4) { dx = q >> 1; dy = q & 1; dz = dx ^ dy; }
+            else { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+            float* base = p.g0_grad + p.g0.at(cl(ax[0].i0, p.g0.nx) + dx, cl(ax[1].i0, p.g0.ny) + dy, DIM == 3 ? cl(ax[2].i0, p.g0.nz) + dz : 0);
+            for (int c = 0; c < C; ++c) atomicAdd(base + c * p.g0.plane, row[q * C + c]);
+        }
+        for (int q = 0; q < K1; ++q) {
+            int dx, dy, dz;
+            if (DIM == 2) { dx = q >> 1; dy = q & 1; dz = 0; }
+            else { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+            float w = 1.0f;
+            if (d.g1_weight_mode != NIC_G1_UNWEIGHTED) {
+                int bits = dx | (dy << 1) | (dz << 2);
+                if (DIM == 3 && d.g1_weight_mode == NIC_G1_REFERENCE) bits = g1_ref_weight_bits(q);
+                w = ((bits & 1) ? ax[0].k1 : 1.0f - ax[0].k1) * ((bits & 2) ? ax[1].k1 : 1.0f - ax[1].k1);
+                if (DIM == 3) w *= (bits & 4) ? ax[2].k1 : 1.0f - ax[2].k1;
+            }
+            float* base = p.g1_grad + p.g1.at(cl(ax[0].i1, p.g1.nx) + dx, cl(ax[1].i1, p.g1.ny) + dy, DIM == 3 ? cl(ax[2].i1, p.g1.nz) + dz : 0);
+            for (int c = 0; c < C; ++c) atomicAdd(base + c * p.g1.plane, row[K0 * C + c] * w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// create_g / create_g_3d / create_g_3d_v2 (fp_def.py:81-112): out[k][c][n] = grid[c, z+dz, y+dy, x+dx]
+__global__ void __launch_bounds__(256) gather_corners_kernel(GridView g, int C, const int32_t* xi, const int32_t* yi, const int32_t* zi,
+                                                             int64_t n, int corner_set, float* out) {
+    const int K = corner_set == 1 ? 8 : 4;
+    const int64_t total = (int64_t)K * C * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % n;
+        const int c = (int)((i / n) % C);
+        const int q = (int)(i / (n * C));
+        int dx, dy, dz;
+        if (corner_set == 0) { dx = q >> 1; dy = q & 1; dz = 0; }
+        else if (corner_set == 1) { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+        else { dx = q >> 1; dy = q & 1; dz = dx ^ dy; }
+        int x = xi[s] + dx, y = yi[s] + dy, z = zi ? zi[s] + dz : 0;
+        x = x < 0 ? 0 : (x >= g.nx ? g.nx - 1 : x);
+        y = y < 0 ? 0 : (y >= g.ny ? g.ny - 1 : y);
+        z = z < 0 ? 0 : (z >= g.nz ? g.nz - 1 : z);
+        out[i] = g.p[(int64_t)c * g.plane + g.at(x, y, z)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct Div8 {
+    float v[8];
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) pe_kernel(const float* coord, int64_t n, int dim, int P, float* out, Div8 dv) {
+    __shared__ float div[8];
+    if (threadIdx.x < 8) div[threadIdx.x] = dv.v[threadIdx.x];
+    __syncthreads();
+    const int64_t total = n * dim * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % n;
+        const int row = (int)(i / n);
+        const int a = row / P, r = row % P;
+        const float c = coord[(int64_t)a * n + s];
+        out[i] = MODE == NIC_PE_TRIANGULAR ? tri_pe_row(c, r, P) : sin_pe_row(c, r, div);
+    }
+}
+
+__global__ void __launch_bounds__(256) lut_gather_kernel(const float* lut, int rows, int seq, const int64_t* coord, int64_t b, int64_t L, float* out) {
+    const int64_t total = b * rows * L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = i % L;
+        const int r = (int)((i / L) % rows);
+        const int64_t bb = i / (L * rows);
+        int64_t c = coord[bb * L + l] % seq;
+        if (c < 0) c += seq;                                    // python / torch remainder
+        out[i] = lut[(int64_t)r * seq + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// quantisers and codec (models.py:29-71).  Division (not reciprocal multiply) like the reference.
+// ---------------------------------------------------------------------------------------------------
+enum { Q_QUANT = 0, Q_TO_BIT = 1 };
+template <int OP>
+__global__ void __launch_bounds__(256) quantize_kernel(const float* src, float* dst, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float q = __fdiv_rn(floorf(__fadd_rn(__fmul_rn(src[i], scale), 0.5f)), scale);
+        dst[i] = OP == Q_QUANT ? q : __fmul_rn(q, scale);
+    }
+}
+__global__ void __launch_bounds__(256) clamp_kernel(float* x, int64_t n, float lo, float hi) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+__global__ void __launch_bounds__(256) save4fp_kernel(const float* src, uint8_t* dst, int64_t n, float scale, float bias) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = __fadd_rn(floorf(__fadd_rn(__fmul_rn(src[i], scale), 0.5f)), bias);
+        dst[i] = (uint8_t)(int)v;                               // torch float -> uint8 cast truncates
+    }
+}
+__global__ void __launch_bounds__(256) load4fp_kernel(const uint8_t* src, float* dst, int64_t n, float scale, float bias) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = __fdiv_rn(__fadd_rn(__fsub_rn((float)src[i], bias), 1.0f), scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PSNR (utils.py:117-130): two-stage fixed-order reduction of the squared error in fp64.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPsnrBlocks = 1024;
+__global__ void __launch_bounds__(256) sqerr_partial_kernel(const float* a, const float* b, int64_t n, double* part) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float dd = a[i] - b[i];
+        acc += (double)dd * (double)dd;
+    }
+    __shared__ double sm[256];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+__global__ void __launch_bounds__(256) psnr_final_kernel(const double* part, int nparts, int64_t n, float peak, float* out2) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mse = (float)(sm[0] / (double)n);
+        out2[0] = mse;
+        out2[1] = mse == 0.f ? INFINITY : 10.0f * log10f(peak * peak / mse);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// torch.optim.Adam single-tensor semantics (default: no weight decay, no amsgrad, eps outside sqrt after
+// bias correction) + the fp_quantize_clamp that follows it (image_compression.py:266-269).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2_sqrt, float lo, float hi) {
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        float x = p[i] - step_size * (mi / denom);
+        if (lo <= hi) x = fminf(fmaxf(x, lo), hi);
+        p[i] = x;
+    }
+}
+
+static inline int blocks_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace nic
+
+using namespace nic;
+
+static int check_desc_common(const nic_path_desc* d) {
+    if (!d) return NIC_E_NULL;
+    if (!((d->dim == 2 && d->method == 1) || (d->dim == 3 && (d->method == 3 || d->method == 4)))) return NIC_E_UNSUPPORTED;
+    if (d->channels < 1 || d->pe_channels < 2 || (d->pe_channels & 1) || d->pe_channels > 16) return NIC_E_UNSUPPORTED;
+    if (d->num_crops < 1) return NIC_E_SHAPE;
+    for (int a = 0; a < d->dim; ++a)
+        if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
+    if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
+    return NIC_OK;
+}
+
+static void make_views(const nic_path_desc* d, const float* g0, const float* g1, GridView& v0, GridView& v1) {
+    v0.p = g0; v0.nx = d->g0_nodes[0]; v0.ny = d->g0_nodes[1]; v0.nz = d->dim == 3 ? d->g0_nodes[2] : 1;
+    v0.plane = (int64_t)v0.nx * v0.ny * v0.nz;
+    v1.p = g1; v1.nx = d->g1_nodes[0]; v1.ny = d->g1_nodes[1]; v1.nz = d->dim == 3 ? d->g1_nodes[2] : 1;
+    v1.plane = (int64_t)v1.nx * v1.ny * v1.nz;
+}
+
+template <bool SPLIT>
+static int encode_impl(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, float* out, void* stream) {
+    int rc = check_desc_common(d);
+    if (rc) return rc;
+    if (!g0 || !g1 || !origins || !out) return NIC_E_NULL;
+    if (SPLIT && d->num_crops != 1) return NIC_E_ARG;
+    EncodeParams p;
+    p.d = *d;
+    make_views(d, g0, g1, p.g0, p.g1);
+    p.origins = origins;
+    p.out = out;
+    p.cin = nic_decoder_input_channels(d->dim, d->method, d->channels, d->pe_channels);
+    p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * (d->dim == 3 ? d->extent[2] : 1);
+    p.n_total = p.n_per_crop * d->num_crops;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = blocks_for(p.n_total);
+    if (d->dim == 2) hipLaunchKernelGGL((encode_kernel<2, SPLIT>), dim3(nb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((encode_kernel<3, SPLIT>), dim3(nb), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" {
+
+int nic_abi_version(void) { return NIC_ABI_VERSION; }
+
+const char* nic_error_string(int code) {
+    switch (code) {
+        case NIC_OK: return "ok";
+        case NIC_E_NULL: return "required pointer is null";
+        case NIC_E_UNSUPPORTED: return "unsupported dim/method/channels/hidden combination";
+        case NIC_E_SHAPE: return "inconsistent extents, node counts or origins";
+        case NIC_E_WORKSPACE: return "workspace too small (see nic_workspace_bytes)";
+        case NIC_E_ARG: return "invalid argument";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int nic_decoder_input_channels(int dim, int method, int channels, int pe_channels) {
+    const int k0 = (dim == 2 || method == 4) ? 4 : 8;          // var2.py:114-118
+    return channels * (k0 + 1) + pe_channels * dim + 1;
+}
+
+int nic_encode(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, float* out, void* stream) {
+    return encode_impl<false>(d, g0, g1, origins, out, stream);
+}
+int nic_encode_split(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, float* out, void* stream) {
+    return encode_impl<true>(d, g0, g1, origins, out, stream);
+}
+
+int nic_encode_backward(const nic_path_desc* d, const int32_t* origins, const float* dx, float* g0_grad, float* g1_grad, void* stream) {
+    int rc = check_desc_common(d);
+    if (rc) return rc;
+    if (!origins || !dx || !g0_grad || !g1_grad) return NIC_E_NULL;
+    EncodeBwdParams p;
+    p.d = *d;
+    make_views(d, nullptr, nullptr, p.g0, p.g1);
+    p.origins = origins; p.dx = dx; p.g0_grad = g0_grad; p.g1_grad = g1_grad;
+    p.cin = nic_decoder_input_channels(d->dim, d->method, d->channels, d->pe_channels);
+    p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * (d->dim == 3 ? d->extent[2] : 1);
+    p.n_total = p.n_per_crop * d->num_crops;
+    const int nb = blocks_for(p.n_total);
+    if (d->dim == 2) hipLaunchKernelGGL((encode_backward_kernel<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((encode_backward_kernel<3>), dim3(nb), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+int nic_gather_corners(const float* grid, int channels, int nx, int ny, int nz, const int32_t* xi, const int32_t* yi, const int32_t* zi,
+                       int64_t n, int corner_set, float* out, void* stream) {
+    if (!grid || !xi || !yi || !out) return NIC_E_NULL;
+    if (channels < 1 || nx < 1 || ny < 1 || nz < 1 || n < 0 || corner_set < 0 || corner_set > 2) return NIC_E_ARG;
+    if ((corner_set != 0) != (zi != nullptr)) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    GridView g;
+    g.p = grid; g.nx = nx; g.ny = ny; g.nz = nz; g.plane = (int64_t)nx * ny * nz;
+    const int K = corner_set == 1 ? 8 : 4;
+    hipLaunchKernelGGL(gather_corners_kernel, dim3(blocks_for((int64_t)K * channels * n)), dim3(256), 0, (hipStream_t)stream, g, channels, xi,
+                       yi, zi, n, corner_set, out);
+    return (int)hipGetLastError();
+}
+
+int nic_positional_encoding(const float* coord, int64_t n, int dim, int P, int pe_mode, const float* pe_div_host, float* out, void* stream) {
+    if (!coord || !out) return NIC_E_NULL;
+    if (n < 0 || dim < 1 || dim > 3 || P < 2 || (P & 1) || P > 16) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = blocks_for(n * dim * P);
+    Div8 dv;
+    for (int i = 0; i < 8; ++i) dv.v[i] = 0.f;
+    if (pe_mode == NIC_PE_TRIANGULAR) {
+        hipLaunchKernelGGL((pe_kernel<NIC_PE_TRIANGULAR>), dim3(nb), dim3(256), 0, s, coord, n, dim, P, out, dv);
+    } else if (pe_mode == NIC_PE_SINUSOIDAL) {
+        if (!pe_div_host) return NIC_E_NULL;
+        for (int i = 0; i < P / 2; ++i) dv.v[i] = pe_div_host[i];      // travels as a kernel argument: no allocation
+        hipLaunchKernelGGL((pe_kernel<NIC_PE_SINUSOIDAL>), dim3(nb), dim3(256), 0, s, coord, n, dim, P, out, dv);
+    } else {
+        return NIC_E_ARG;
+    }
+    return (int)hipGetLastError();
+}
+
+int nic_lut_gather(const float* lut, int rows, int seq_len, const int64_t* coord, int64_t b, int64_t L, float* out, void* stream) {
+    if (!lut || !coord || !out) return NIC_E_NULL;
+    if (rows < 1 || seq_len < 1 || b < 0 || L < 0) return NIC_E_ARG;
+    if (b * L == 0) return NIC_OK;
+    hipLaunchKernelGGL(lut_gather_kernel, dim3(blocks_for(b * rows * L)), dim3(256), 0, (hipStream_t)stream, lut, rows, seq_len, coord, b, L, out);
+    return (int)hipGetLastError();
+}
+
+int nic_quantize(const float* src, float* dst, int64_t n, int num_bits, void* stream) {
+    if (!src || !dst) return NIC_E_NULL;
+    if (num_bits < 1 || num_bits > 16 || n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipLaunchKernelGGL((quantize_kernel<Q_QUANT>), dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, (float)((1 << num_bits) - 1));
+    return (int)hipGetLastError();
+}
+int nic_quantize_to_bit(const float* src, float* dst, int64_t n, int num_bits, void* stream) {
+    if (!src || !dst) return NIC_E_NULL;
+    if (num_bits < 1 || num_bits > 16 || n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipLaunchKernelGGL((quantize_kernel<Q_TO_BIT>), dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, (float)((1 << num_bits) - 1));
+    return (int)hipGetLastError();
+}
+int nic_clamp(float* x, int64_t n, float lo, float hi, void* stream) {
+    if (!x) return NIC_E_NULL;
+    if (n <= 0) return n == 0 ? NIC_OK : NIC_E_ARG;
+    hipLaunchKernelGGL(clamp_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, lo, hi);
+    return (int)hipGetLastError();
+}
+int nic_save4fp_u8(const float* src, uint8_t* dst, int64_t n, int num_bits, void* stream) {
+    if (!src || !dst) return NIC_E_NULL;
+    if (num_bits < 1 || num_bits > 8 || n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipLaunchKernelGGL(save4fp_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, (float)((1 << num_bits) - 1),
+                       (float)((1 << (num_bits - 1)) - 1));
+    return (int)hipGetLastError();
+}
+int nic_load4fp_u8(const uint8_t* src, float* dst, int64_t n, int num_bits, void* stream) {
+    if (!src || !dst) return NIC_E_NULL;
+    if (num_bits < 1 || num_bits > 8 || n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipLaunchKernelGGL(load4fp_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, (float)((1 << num_bits) - 1),
+                       (float)(1 << (num_bits - 1)));
+    return (int)hipGetLastError();
+}
+
+int nic_psnr(const float* a, const float* b, int64_t n, int num_bits, float* out2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a || !b || !out2 || !workspace) return NIC_E_NULL;
+    if (n <= 0 || num_bits < 1 || num_bits > 24) return NIC_E_ARG;
+    if (workspace_bytes < sizeof(double) * kPsnrBlocks) return NIC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int nb = blocks_for(n);
+    if (nb > kPsnrBlocks) nb = kPsnrBlocks;
+    hipLaunchKernelGGL(sqerr_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, n, (double*)workspace);
+    hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, n, (float)(1 << num_bits), out2);
+    return (int)hipGetLastError();
+}
+
+int nic_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t step, float clamp_lo, float clamp_hi, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return NIC_E_NULL;
+    if (n <= 0 || step < 1) return n == 0 ? NIC_OK : NIC_E_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, (float)bc1, (float)sqrt(bc2), clamp_lo, clamp_hi);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

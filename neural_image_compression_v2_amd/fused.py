@@ -1,0 +1,413 @@
+"""Host side of the fused gfx950 kernels: geometry descriptors, argument validation, autograd glue.
+
+Everything here is plumbing above the C ABI (include/nicv2_hip.h); the arithmetic of the path runs in
+libnicv2_hip.so.  Reference citations are relative to /root/reference/Projects.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field, replace
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import (NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED, NIC_NOISE_NONE, NIC_NOISE_PHILOX,
+                   NIC_NOISE_TENSOR, NIC_PE_SINUSOIDAL, NIC_PE_TRIANGULAR)
+
+
+def g1_weights_enabled(step_number) -> bool:
+    """the reference's guard, evaluated the way it writes it (fp_def.py:136,170,209)"""
+    return int(1 // (step_number / 2)) != 1
+
+
+def log2_step_of(step_number) -> int:
+    e = round(math.log2(step_number))
+    if 2.0 ** e != float(step_number):
+        raise ValueError(f"step_number must be a power of two (image_compression.py:79), got {step_number}")
+    return int(e)
+
+
+def sinusoidal_div_term(num_channels: int) -> List[float]:
+    """div_term exactly as torch evaluates it in fp32 (utils.py:202); 3 numbers, computed on the host"""
+    t = torch.exp(torch.arange(0, num_channels, 2, dtype=torch.float32) * -(math.log(10000.0) / num_channels))
+    return [float(v) for v in t]
+
+
+def decoder_input_channels(dim: int, method: int, channels: int, pe_channels: int) -> int:
+    """Cin (var2.py:114-118)"""
+    k0 = 4 if (dim == 2 or method == 4) else 8
+    return channels * (k0 + 1) + pe_channels * dim + 1
+
+
+@dataclass
+class PathGeometry:
+    """Python mirror of nic_path_desc: which grid pair, which samples (arguments of create_g0_g1* and
+    create_decoder_input_*, fp_def.py:115-223, image_compression.py:71-167)."""
+    dim: int
+    method: int                      # 1: 2D, 3: 3D full corners, 4: 3D tetrahedral G0
+    step_number: Union[int, float]   # 2^(mip - 2(fl+1))
+    mip_level: float
+    extent: Tuple[int, ...]          # samples per axis of a crop (x first)
+    num_crops: int
+    channels: int = 12
+    pe_channels: int = 6
+    hidden: int = 64
+    use_tri_pe: bool = True
+    textbook_weights: bool = False
+    noise_mode: int = NIC_NOISE_NONE
+    num_bits: int = 8
+    philox_seed: int = 0
+    philox_offset: int = 0
+    sample_base: int = 0
+    loss_scale: Optional[float] = None   # default 1 / (3 N)
+
+    def __post_init__(self):
+        if self.dim == 3 and self.method == 3:
+            self.use_tri_pe = True           # fp_def.py:169
+        if self.dim == 3 and self.method == 4:
+            self.use_tri_pe = False          # fp_def.py:208
+        if len(self.extent) != self.dim:
+            raise ValueError("extent needs one entry per axis")
+
+    @property
+    def n_per_crop(self) -> int:
+        n = 1
+        for e in self.extent:
+            n *= int(e)
+        return n
+
+    @property
+    def n_samples(self) -> int:
+        return self.n_per_crop * self.num_crops
+
+    @property
+    def cin(self) -> int:
+        return decoder_input_channels(self.dim, self.method, self.channels, self.pe_channels)
+
+    def g1_mode(self) -> int:
+        if not g1_weights_enabled(self.step_number):
+            return NIC_G1_UNWEIGHTED                                   # Q6
+        return NIC_G1_TEXTBOOK if self.textbook_weights else NIC_G1_REFERENCE
+
+    def to_desc(self, g0: torch.Tensor, g1: torch.Tensor) -> _lib.NicPathDesc:
+        d = _lib.NicPathDesc()
+        d.dim, d.method = self.dim, self.method
+        d.channels, d.pe_channels, d.hidden = self.channels, self.pe_channels, self.hidden
+        d.pe_mode = NIC_PE_TRIANGULAR if self.use_tri_pe else NIC_PE_SINUSOIDAL
+        d.g1_weight_mode = self.g1_mode()
+        d.log2_step = log2_step_of(self.step_number)
+        d.lod_value = float(self.mip_level)
+        d.num_crops = int(self.num_crops)
+        for a in range(3):
+            d.extent[a] = int(self.extent[a]) if a < self.dim else 1
+            # tensor is [C, (Z,) Y, X]: axis a of the samples is tensor dim -(a+1)
+            d.g0_nodes[a] = int(g0.shape[-(a + 1)]) if a < self.dim else 1
+            d.g1_nodes[a] = int(g1.shape[-(a + 1)]) if a < self.dim else 1
+        div = sinusoidal_div_term(self.pe_channels)
+        for i in range(8):
+            d.pe_div[i] = div[i] if i < len(div) else 0.0
+        d.noise_mode = int(self.noise_mode)
+        d.num_bits = int(self.num_bits)
+        d.philox_seed = int(self.philox_seed) & 0xFFFFFFFFFFFFFFFF
+        d.philox_offset = int(self.philox_offset) & 0xFFFFFFFFFFFFFFFF
+        d.sample_base = int(self.sample_base)
+        d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
+        return d
+
+
+def check_grids(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor) -> None:
+    for name, g in (("G0", g0), ("G1", g1)):
+        if g.dim() != geo.dim + 1 or g.shape[0] != geo.channels:
+            raise ValueError(f"{name} must be [C={geo.channels}" + ", n" * geo.dim + f"], got {tuple(g.shape)}")
+
+
+def check_origins(geo: PathGeometry, origins_host: torch.Tensor, g0: torch.Tensor, g1: torch.Tensor) -> None:
+    """Host-side bounds check: every corner index must stay inside its grid (the reference would raise
+    IndexError from advanced indexing; the kernels clamp for memory safety only)."""
+    o = origins_host.reshape(-1, geo.dim).to(torch.int64)
+    if o.shape[0] != geo.num_crops:
+        raise ValueError(f"need {geo.num_crops} origins, got {o.shape[0]}")
+    if bool((o < 0).any()):
+        raise IndexError("negative crop origin")
+    s = float(geo.step_number)
+    for a in range(geo.dim):
+        qmax = int(o[:, a].max()) + int(geo.extent[a]) - 1
+        i0 = math.floor(qmax * s) + 1
+        i1 = math.floor(qmax * s / 2) + 1
+        n0, n1 = int(g0.shape[-(a + 1)]), int(g1.shape[-(a + 1)])
+        if i0 > n0 - 1 or i1 > n1 - 1:
+            raise IndexError(f"axis {a}: corner index {i0}/{i1} outside grids with {n0}/{n1} nodes "
+                             f"(origin+extent {qmax + 1}, step {geo.step_number})")
+
+
+def upload_origins(geo: PathGeometry, coord, device, g0=None, g1=None) -> torch.Tensor:
+    """int32 [num_crops, dim] on the device.  Host inputs (list / CPU tensor) are validated first; a
+    device tensor is taken as is (validating it would force a sync)."""
+    if isinstance(coord, torch.Tensor) and coord.is_cuda:
+        return coord.reshape(-1, geo.dim).to(torch.int32).contiguous()
+    host = torch.as_tensor(coord).reshape(-1, geo.dim).to(torch.int64)
+    if g0 is not None:
+        check_origins(geo, host, g0, g1)
+    return host.to(torch.int32).to(device, non_blocking=True)
+
+
+def _mlp_struct(params: Sequence[torch.Tensor]) -> _lib.NicMlp:
+    """params in nn.Sequential order: W1, b1, W2, b2, W3, b3"""
+    m = _lib.NicMlp()
+    for i in range(3):
+        m.w[i] = params[2 * i].data_ptr()
+        m.b[i] = params[2 * i + 1].data_ptr()
+    return m
+
+
+def _grads_struct(grads: Sequence[Optional[torch.Tensor]]) -> _lib.NicMlpGrads:
+    g = _lib.NicMlpGrads()
+    for i in range(3):
+        g.w[i] = 0 if grads[2 * i] is None else grads[2 * i].data_ptr()
+        g.b[i] = 0 if grads[2 * i + 1] is None else grads[2 * i + 1].data_ptr()
+    return g
+
+
+def check_mlp(params: Sequence[torch.Tensor], cin: int, hidden: int) -> List[torch.Tensor]:
+    shapes = [(hidden, cin), (hidden,), (hidden, hidden), (hidden,), (3, hidden), (3,)]
+    out = []
+    for t, s, n in zip(params, shapes, ("W1", "b1", "W2", "b2", "W3", "b3")):
+        t = _lib.require_cuda_f32(t, n)
+        if tuple(t.shape) != s:
+            raise ValueError(f"decoder parameter {n} has shape {tuple(t.shape)}, expected {s}")
+        out.append(t)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# plain calls
+# ------------------------------------------------------------------------------------------------------
+
+def encode(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -> torch.Tensor:
+    """[N, Cin] decoder input (create_decoder_input_* / finally_decode_input_*, image_compression.py:71-211)"""
+    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
+    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    check_grids(geo, g0, g1)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    out = torch.empty(geo.n_samples, geo.cin, dtype=torch.float32, device=g0.device)
+    d = geo.to_desc(g0, g1)
+    _lib.check(_lib.load().nic_encode(ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), _lib.ptr(out),
+                                      _lib.stream_ptr(g0.device)), "nic_encode")
+    return out
+
+
+def encode_split(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -> torch.Tensor:
+    """[K0*C + K1*C + P*D, n] rows for ONE crop (create_g0_g1*, fp_def.py:115-223)"""
+    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
+    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    check_grids(geo, g0, g1)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    k0 = 4 if (geo.dim == 2 or geo.method == 4) else 8
+    k1 = 4 if geo.dim == 2 else 8
+    rows = (k0 + k1) * geo.channels + geo.pe_channels * geo.dim
+    out = torch.empty(rows, geo.n_per_crop, dtype=torch.float32, device=g0.device)
+    d = geo.to_desc(g0, g1)
+    _lib.check(_lib.load().nic_encode_split(ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), _lib.ptr(out),
+                                            _lib.stream_ptr(g0.device)), "nic_encode_split")
+    return out
+
+
+def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N, 3]: encode (+ noise) + decoder in one kernel (decode_image's inner step, image_compression.py:313-345)"""
+    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
+    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    check_grids(geo, g0, g1)
+    params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    if geo.noise_mode == NIC_NOISE_TENSOR:
+        noise = _lib.require_cuda_f32(noise, "noise")
+        if tuple(noise.shape) != (geo.n_samples, geo.cin):
+            raise ValueError("noise must be [N, Cin]")
+    y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0.device)
+    d = geo.to_desc(g0, g1)
+    m = _mlp_struct(params)
+    _lib.check(_lib.load().nic_fused_forward(ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
+                                             _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(y),
+                                             _lib.stream_ptr(g0.device)), "nic_fused_forward")
+    return y
+
+
+@dataclass
+class StepOutput:
+    loss: torch.Tensor                       # 0-dim, the MSE mean (image_compression.py:259)
+    y: Optional[torch.Tensor]
+    grad_g0: torch.Tensor
+    grad_g1: torch.Tensor
+    grad_mlp: List[torch.Tensor]             # W1, b1, W2, b2, W3, b3
+    flat: torch.Tensor                       # one buffer holding [loss | decoder grads | grid grads]
+
+
+def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor):
+    """offsets (in floats) of [loss, W1, b1, W2, b2, W3, b3, G0, G1] inside one flat gradient buffer -
+    one buffer so that data-parallel training needs a single all-reduce per step."""
+    H, cin = geo.hidden, geo.cin
+    sizes = [4, H * cin, H, H * H, H, 3 * H, 3, g0.numel(), g1.numel()]      # loss padded to 16 B
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(o)
+        o += (s + 3) // 4 * 4
+    return offs, sizes, o
+
+
+def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: torch.Tensor,
+                           noise: Optional[torch.Tensor] = None, want_y: bool = False,
+                           flat: Optional[torch.Tensor] = None) -> StepOutput:
+    """One training step's forward + MSE + backward in one launch (+ the fixed-order partial reduction):
+    image_compression.py:239-265.  Gradients are returned, not accumulated into .grad."""
+    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
+    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    check_grids(geo, g0, g1)
+    params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    target = _lib.require_cuda_f32(target, "target").reshape(-1, 3)
+    if target.shape[0] != geo.n_samples:
+        raise ValueError(f"target has {target.shape[0]} rows, geometry has {geo.n_samples} samples")
+    if geo.noise_mode == NIC_NOISE_TENSOR:
+        noise = _lib.require_cuda_f32(noise, "noise")
+        if tuple(noise.shape) != (geo.n_samples, geo.cin):
+            raise ValueError("noise must be [N, Cin]")
+    dev = g0.device
+    offs, sizes, total = grad_bucket_layout(geo, g0, g1)
+    if flat is None:
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)       # grid grads must start at zero
+    else:
+        if flat.numel() != total or flat.dtype != torch.float32 or not flat.is_cuda:
+            raise ValueError("flat gradient buffer has the wrong size / dtype / device")
+        flat.zero_()
+    views = [flat[o:o + s] for o, s in zip(offs, sizes)]
+    shapes = [p.shape for p in params]
+    gm = [views[1 + i].view(shapes[i]) for i in range(6)]
+    gg0, gg1 = views[7].view(g0.shape), views[8].view(g1.shape)
+    y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=dev) if want_y else None
+    d = geo.to_desc(g0, g1)
+    lib = _lib.load()
+    ws_bytes = int(lib.nic_workspace_bytes(ctypes.byref(d)))
+    ws = _lib.workspace(dev, ws_bytes)
+    m = _mlp_struct(params)
+    gs = _grads_struct(gm)
+    _lib.check(lib.nic_fused_forward_backward(
+        ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
+        _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(target), _lib.ptr(y), _lib.ptr(views[0]),
+        _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_forward_backward")
+    return StepOutput(views[0][0], y, gg0, gg1, gm, flat)
+
+
+# ------------------------------------------------------------------------------------------------------
+# autograd
+# ------------------------------------------------------------------------------------------------------
+
+class FusedGridMLP(torch.autograd.Function):
+    """y[N,3] = decoder(encode(G0, G1) + noise) as ONE differentiable op.  Inputs are the caller's own leaf
+    tensors (the reference keeps the grids as raw leaves in a Python list registered in Adam,
+    image_compression.py:361-364), read by pointer on every call.  backward() recomputes the forward inside
+    the backward kernel and returns dense gradients of the grids' shapes."""
+
+    @staticmethod
+    def forward(ctx, g0, g1, w1, b1, w2, b2, w3, b3, geo: PathGeometry, org: torch.Tensor, noise):
+        params = [w1, b1, w2, b2, w3, b3]
+        y = fused_forward(geo, g0, g1, org, params, noise)
+        ctx.save_for_backward(g0, g1, *params)
+        ctx.geo, ctx.org, ctx.noise = geo, org, noise
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g0, g1, *params = ctx.saved_tensors
+        geo = ctx.geo
+        g0c = _lib.require_cuda_f32(g0.detach(), "G0")
+        g1c = _lib.require_cuda_f32(g1.detach(), "G1")
+        pc = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
+        dy = _lib.require_cuda_f32(dy, "dy")
+        dev = g0c.device
+        gg0, gg1 = torch.zeros_like(g0c), torch.zeros_like(g1c)
+        gm = [torch.empty_like(p) for p in pc]
+        d = geo.to_desc(g0c, g1c)
+        lib = _lib.load()
+        ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(ctypes.byref(d))))
+        m, gs = _mlp_struct(pc), _grads_struct(gm)
+        noise = ctx.noise if geo.noise_mode == NIC_NOISE_TENSOR else None
+        _lib.check(lib.nic_fused_backward_dy(ctypes.byref(d), _lib.ptr(g0c), _lib.ptr(g1c), _lib.ptr(ctx.org), ctypes.byref(m),
+                                             _lib.ptr(noise), _lib.ptr(dy), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs),
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_backward_dy")
+        need = ctx.needs_input_grad
+        grads = [gg0 if need[0] else None, gg1 if need[1] else None] + [gm[i] if need[2 + i] else None for i in range(6)]
+        return (*grads, None, None, None)
+
+
+def fused_grid_mlp(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """differentiable fused op (see FusedGridMLP)"""
+    check_grids(geo, g0, g1)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    if geo.noise_mode == NIC_NOISE_TENSOR:
+        noise = _lib.require_cuda_f32(noise, "noise")
+    return FusedGridMLP.apply(g0, g1, *params, geo, org, noise)
+
+
+class EncodeFunction(torch.autograd.Function):
+    """create_decoder_input_* as a differentiable op: forward nic_encode, backward nic_encode_backward (dense grid
+    gradients, like autograd through the reference's advanced-indexing gathers)."""
+
+    @staticmethod
+    def forward(ctx, g0, g1, geo: PathGeometry, org: torch.Tensor):
+        ctx.geo, ctx.org = geo, org
+        ctx.shapes = (g0.shape, g1.shape)
+        ctx.dev = g0.device
+        return encode(geo, g0, g1, org)
+
+    @staticmethod
+    def backward(ctx, dx):
+        geo = ctx.geo
+        dx = _lib.require_cuda_f32(dx, "dx")
+        gg0 = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=ctx.dev)
+        gg1 = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=ctx.dev)
+        d = geo.to_desc(gg0, gg1)
+        _lib.check(_lib.load().nic_encode_backward(ctypes.byref(d), _lib.ptr(ctx.org), _lib.ptr(dx), _lib.ptr(gg0), _lib.ptr(gg1),
+                                                   _lib.stream_ptr(ctx.dev)), "nic_encode_backward")
+        return gg0, gg1, None, None
+
+
+def encode_differentiable(geo: PathGeometry, g0, g1, coord) -> torch.Tensor:
+    check_grids(geo, g0, g1)
+    org = upload_origins(geo, coord, g0.device, g0, g1)
+    if not (g0.requires_grad or g1.requires_grad):
+        return encode(geo, g0, g1, org)
+    return EncodeFunction.apply(g0, g1, geo, org)
+
+
+class DecoderFunction(torch.autograd.Function):
+    """ColorDecoder.forward on an explicit [n, Cin] input (image_compression.py:66-68) and its backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
+        params = check_mlp([w1, b1, w2, b2, w3, b3], x.shape[1], w2.shape[0])
+        xc = _lib.require_cuda_f32(x, "x")
+        n, cin = xc.shape
+        y = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
+        m = _mlp_struct(params)
+        _lib.check(_lib.load().nic_decoder_forward(ctypes.byref(m), _lib.ptr(xc), n, cin, w2.shape[0], _lib.ptr(y),
+                                                   _lib.stream_ptr(xc.device)), "nic_decoder_forward")
+        ctx.save_for_backward(xc, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *params = ctx.saved_tensors
+        dy = _lib.require_cuda_f32(dy, "dy")
+        n, cin = x.shape
+        dev = x.device
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        gm = [torch.empty_like(p) for p in params]
+        lib = _lib.load()
+        ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(None)))
+        m, gs = _mlp_struct(params), _grads_struct(gm)
+        _lib.check(lib.nic_decoder_backward(ctypes.byref(m), _lib.ptr(x), _lib.ptr(dy), n, cin, params[2].shape[0], _lib.ptr(dx),
+                                            ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_decoder_backward")
+        return (dx, *[gm[i] if need[1 + i] else None for i in range(6)])

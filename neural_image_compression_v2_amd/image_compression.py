@@ -1,0 +1,236 @@
+"""Driver-level call surface of the reference's Projects/image_compression.py for the hot path:
+ColorDecoder, create_decoder_input_2d/_3d/_3d_v2, finally_decode_input_*, random_crop_dataset, train_models,
+decode_image - with the same names, argument meaning and channel / sample orders, running on the HIP library.
+
+The reference is a script that reads module globals from var2.py; here the same names live in a
+``var2.Settings`` object held by ``ImageCompression``, whose methods keep the reference signatures.
+``train_models`` offers the reference's unfused sequence (differentiable encode -> noise -> decoder -> MSELoss ->
+backward; every op a HIP kernel of this package) and the fused single-launch step (default).
+"""
+from __future__ import annotations
+
+import math
+import random
+import time
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib, fused
+from .fp_def import (create_pyramid, create_pyramid_3d, create_pyramid_mip_levels, fp_all_quantize, fp_freeze,
+                     fp_quantize_clamp)
+from .models import quantize_to_bit
+from .utils import calculate_psnr
+from .var2 import Settings
+
+
+class ColorDecoder(nn.Module):
+    """Linear(Cin,H)-GELU-Linear(H,H)-GELU-Linear(H,3)-Sigmoid (image_compression.py:54-68).  The nn.Sequential only
+    owns the parameters (state_dict keys decoder.{0,2,4}.{weight,bias}, default nn.Linear init); forward() runs the
+    whole stack in one HIP kernel (nic_decoder_forward) with its own autograd backward (nic_decoder_backward)."""
+
+    def __init__(self, decoder_input_channels: int = 73, hidden_layer_channels: int = 64):
+        super().__init__()
+        self.decoder = nn.Sequential(
+            nn.Linear(decoder_input_channels, hidden_layer_channels), nn.GELU(),
+            nn.Linear(hidden_layer_channels, hidden_layer_channels), nn.GELU(),
+            nn.Linear(hidden_layer_channels, 3), nn.Sigmoid())
+
+    def linear_params(self) -> List[torch.Tensor]:
+        d = self.decoder
+        return [d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias]
+
+    def forward(self, x):
+        return fused.DecoderFunction.apply(x, *self.linear_params())
+
+
+class ImageCompression:
+    """State + methods of the reference script for one fit."""
+
+    def __init__(self, cfg: Optional[Settings] = None, device=None, seed: Optional[int] = None):
+        self.cfg = cfg or Settings()
+        c = self.cfg
+        self.device = torch.device(device) if device is not None else c.DEVICE
+        if self.device.type != "cuda":
+            raise RuntimeError("ImageCompression needs a HIP device: there is no CPU implementation of this path")
+        if c.MLP_NUM_DTYPE != 32:
+            raise NotImplementedError("MLP_NUM_DTYPE=32 only (the reference's 16-bit path is unfinished, readme.md:9)")
+        if seed is not None:
+            torch.manual_seed(seed)
+            random.seed(seed)
+        self.decoder = ColorDecoder(c.DECODER_INPUT_CHANNELS, c.HIDDEN_LAYER_CHANNELS).to(self.device)     # :350
+        pyr = create_pyramid if c.FP_DIMENSION == 2 else create_pyramid_3d
+        self.feature_pyramid, self.feature_pyramid_levels = pyr(c.FEATURE_PYRAMID_SIZE, c.FEATURE_PYRAMID_CHANNELS, c.FP_BITS,
+                                                                 self.device, torch.float32, c.TF_NO_MIP)    # :352-357
+        self.feature_pyramid_mip_levels_dict = create_pyramid_mip_levels(c.IMAGE_SIZE, c.FEATURE_PYRAMID_SIZE)  # :360
+        self.optimizer = torch.optim.Adam([{"params": self.feature_pyramid, "lr": 0.01},
+                                           {"params": self.decoder.parameters(), "lr": 0.005}])            # :361-364
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365
+        self.images: List[torch.Tensor] = []
+        self.loss_history: List[torch.Tensor] = []
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ geometry helpers
+    def _method(self) -> int:
+        return self.cfg.COMPRESSION_METHOD if self.cfg.FP_DIMENSION == 3 else 1
+
+    def _geometry(self, fl, mip_level, sample_number, num_crops, method=None, **kw) -> fused.PathGeometry:
+        c = self.cfg
+        D = c.FP_DIMENSION
+        return fused.PathGeometry(dim=D, method=method or self._method(), step_number=pow(2, mip_level - (fl + 1) * 2), mip_level=mip_level,
+                                  extent=(sample_number,) * D, num_crops=num_crops, channels=c.FEATURE_PYRAMID_CHANNELS,
+                                  pe_channels=c.PE_CHANNELS, hidden=c.HIDDEN_LAYER_CHANNELS, use_tri_pe=c.TF_USE_TRI_PE,
+                                  num_bits=c.FP_BITS, **kw)
+
+    def train_sample_number(self, mip_level: int) -> int:
+        """2D hard-codes 2^max(0, 8 - mip) (image_compression.py:78); 3D uses CROP_MIP_LEVEL (:110,144)"""
+        if self.cfg.FP_DIMENSION == 2:
+            return pow(2, max(0, 8 - mip_level))
+        return pow(2, max(0, self.cfg.CROP_MIP_LEVEL - mip_level))
+
+    # ------------------------------------------------------------------ decoder input builders
+    def create_decoder_input_2d(self, fp, coord, num_crops, fl, mip_level):
+        """[N, Cin] for ``num_crops`` crops at ``coord`` (image_compression.py:71-100); differentiable w.r.t. fp"""
+        geo = self._geometry(fl, mip_level, pow(2, max(0, 8 - mip_level)), num_crops)
+        return fused.encode_differentiable(geo, fp[2 * fl], fp[2 * fl + 1], coord)
+
+    def create_decoder_input_3d(self, fp, coord, num_crops, fl, mip_level, _method=3):
+        """8 raw G0 corners + permuted-weight G1 blend + triangular PE (image_compression.py:103-134)"""
+        geo = self._geometry(fl, mip_level, pow(2, max(0, self.cfg.CROP_MIP_LEVEL - mip_level)), num_crops, method=_method)
+        return fused.encode_differentiable(geo, fp[2 * fl], fp[2 * fl + 1], coord)
+
+    def create_decoder_input_3d_v2(self, fp, coord, num_crops, fl, mip_level):
+        """4 tetrahedral G0 corners + G1 blend + sinusoidal PE (image_compression.py:137-167)"""
+        return self.create_decoder_input_3d(fp, coord, num_crops, fl, mip_level, _method=4)
+
+    def finally_decode_input_2d(self, fp, image_size, mip_level, x=0, y=0):
+        """one tile of side ``image_size`` at origin (x, y) (image_compression.py:170-181)"""
+        fl = self.feature_pyramid_mip_levels_dict[mip_level]
+        return fused.encode(self._geometry(fl, mip_level, image_size, 1), fp[2 * fl], fp[2 * fl + 1], [[x, y]])
+
+    def finally_decode_input_3d(self, fp, image_size, mip_level, x=0, y=0, z=0, _method=3):
+        """image_compression.py:184-196"""
+        fl = self.feature_pyramid_mip_levels_dict[mip_level]
+        return fused.encode(self._geometry(fl, mip_level, image_size, 1, method=_method), fp[2 * fl], fp[2 * fl + 1], [[x, y, z]])
+
+    def finally_decode_input_3d_v2(self, fp, image_size, mip_level, x=0, y=0, z=0):
+        """image_compression.py:199-211"""
+        return self.finally_decode_input_3d(fp, image_size, mip_level, x, y, z, _method=4)
+
+    # ------------------------------------------------------------------ sampler (image_compression.py:26-50)
+    def random_crop_dataset(self, datasets, crop_size, num_crops, uniform_distribution, dim=2):
+        """LOD from python ``random``, ``num_crops`` origins from torch.randint on the CPU generator (one range for all
+        axes), targets [num_crops, n, 3] sliced from the resident image; returns (targets, origins (host), lod)."""
+        c = self.cfg
+        if uniform_distribution:
+            lod = random.randint(0, c.MAX_MIP_LEVEL)
+        else:
+            lod = min(int(math.floor(-math.log2(random.random()) / 2)), c.MAX_MIP_LEVEL)
+        dataset = datasets[lod]
+        data_size = dataset.shape[1]
+        re_crop = max(1, crop_size // pow(2, lod))
+        crops, coord = [], []
+        for _ in range(num_crops):
+            start = torch.randint(0, data_size - re_crop + 1, (dim,))
+            sl = tuple(slice(int(start[d]), int(start[d]) + re_crop) for d in range(dim))
+            crops.append(dataset[(slice(None), *sl)].reshape(3, -1).T)
+            coord.append(start)
+        return torch.stack(crops), torch.stack(coord), lod
+
+    # ------------------------------------------------------------------ one training iteration
+    def train_step(self, fp, epoch: int, fused_step: bool = True, noise_seed: int = 7):
+        """body of the loop in train_models (image_compression.py:221-269); returns the loss (device scalar)"""
+        c = self.cfg
+        D = c.FP_DIMENSION
+        inputs, coord, lod = self.random_crop_dataset(self.images, c.CROP_SIZE, c.NUM_CROPS, self._uniform(), dim=D)
+        fl = self.feature_pyramid_mip_levels_dict[lod]
+        noisy = epoch < c.NUM_EPOCHS * 0.95
+        target = inputs.reshape(-1, 3)
+        if fused_step and fp[2 * fl].requires_grad:
+            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
+                                 noise_mode=_lib.NIC_NOISE_PHILOX if noisy else _lib.NIC_NOISE_NONE,
+                                 philox_seed=noise_seed, philox_offset=epoch)
+            out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target)
+            self.optimizer.zero_grad(set_to_none=True)
+            fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1
+            for p, g in zip(self.decoder.linear_params(), out.grad_mlp):
+                p.grad = g
+            loss = out.loss
+        else:
+            if D == 2:
+                x = self.create_decoder_input_2d(fp, coord, c.NUM_CROPS, fl, lod)
+            elif c.COMPRESSION_METHOD == 4:
+                x = self.create_decoder_input_3d_v2(fp, coord, c.NUM_CROPS, fl, lod)
+            else:
+                x = self.create_decoder_input_3d(fp, coord, c.NUM_CROPS, fl, lod)
+            if noisy:
+                x = x + (torch.rand_like(x) - 0.5) / (2 ** c.FP_BITS)                                   # :250
+            y = self.decoder(x)
+            loss = ((y - target) ** 2).mean()                                                          # nn.MSELoss (:259)
+            self.optimizer.zero_grad()
+            loss.backward()
+        self.optimizer.step()
+        self.scheduler.step()
+        fp_quantize_clamp(fp, fl, c.FP_BITS)                                                           # :269
+        return loss.detach()
+
+    def _uniform(self) -> bool:
+        self._acc = getattr(self, "_acc", 0.0) + self.cfg.UNIFORM_DISTRIBUTION_RATE                    # :221-226
+        if self._acc >= 1.0:
+            self._acc -= 1.0
+            return True
+        return False
+
+    def train_models(self, fp, fused_step: bool = True, log_every: int = 0):
+        """image_compression.py:215-303 without the tensorboard / file side effects.  After 95 % of the steps the grids are
+        frozen and training continues on quantised copies (local rebinding, like the reference); losses stay on the
+        device (no per-step host sync)."""
+        c = self.cfg
+        frozen = False
+        for epoch in range(c.NUM_EPOCHS):
+            if epoch > c.NUM_EPOCHS * 0.95 and not frozen:
+                fp_freeze(fp)
+                fp = fp_all_quantize(fp, c.FP_BITS)
+                frozen = True
+            loss = self.train_step(fp, epoch, fused_step)
+            self.loss_history.append(loss)
+            self.step_count += 1
+            if log_every and (epoch + 1) % log_every == 0:
+                print(f"Epoch [{epoch + 1}/{c.NUM_EPOCHS}], Loss: {loss.item():.4f}", flush=True)
+        return fp
+
+    # ------------------------------------------------------------------ decode (image_compression.py:307-346)
+    def decode_image(self, fp, arc_decoder, mip_level, pr=False, div_size=10):
+        """full image at ``mip_level`` as [S, S(, S), 3] (first axis = x): one fused encode+decoder launch per tile, tiles of
+        side <= 2^div_size like the reference"""
+        c = self.cfg
+        D = c.FP_DIMENSION
+        with torch.no_grad():
+            power = c.MAX_MIP_LEVEL - mip_level
+            div_slice = pow(2, max(power - div_size, 0))
+            decode_size = c.IMAGE_SIZE // pow(2, mip_level)
+            fl = self.feature_pyramid_mip_levels_dict[mip_level]
+            params = arc_decoder.linear_params()
+            if div_slice == 1:
+                geo = self._geometry(fl, mip_level, decode_size, 1)
+                y = fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], [[0] * D], params)
+                return y.reshape(*([decode_size] * D), 3)
+            if D != 2:
+                raise NotImplementedError("tiled decode is 2D only, like the reference (image_compression.py:329-345)")
+            s = decode_size // div_slice
+            result = torch.zeros(decode_size, decode_size, 3, dtype=torch.float32, device=self.device)
+            geo = self._geometry(fl, mip_level, s, 1)
+            for i in range(div_slice * div_slice):
+                tx, ty = i % div_slice, i // div_slice
+                y = fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], [[s * tx, s * ty]], params)
+                result[s * tx:s * (tx + 1), s * ty:s * (ty + 1), :] = y.reshape(s, s, 3)
+            return result
+
+    def psnr(self, fp, mip_level: int = 0):
+        """PSNR (peak 256) of the decode against the resident image (image_compression.py:283-289)"""
+        D = self.cfg.FP_DIMENSION
+        rec = self.decode_image(fp, self.decoder, mip_level)
+        perm = (1, 2, 0) if D == 2 else (1, 2, 3, 0)
+        ref = self.images[mip_level].permute(*perm).contiguous()
+        return calculate_psnr(quantize_to_bit(rec, self.cfg.OUTPUT_BITS), quantize_to_bit(ref, self.cfg.OUTPUT_BITS))

@@ -1,0 +1,89 @@
+"""Configuration: the names of the reference's Projects/var2.py as a dataclass.  The reference sets module
+globals and overrides them from ``NAME=value`` argv with exec (var2.py:90-95); here the same names are fields,
+``from_argv`` parses the same syntax without exec, and the derived values (var2.py:107-123) are properties.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+from typing import Sequence
+
+import torch
+
+from .utils import bits2dtype_torch, judge_value
+
+_TYPES = {int: "int", float: "float", bool: "bool", str: "str"}
+
+
+@dataclass
+class Settings:
+    IMAGE_PATH: str = "data/sancho_512.png"
+    PROJECT_NAME: str = "image_compression"
+    IMAGE_DTYPE: str = "image"
+    COMPRESSION_METHOD: int = 1          # 1: 2D, 2: 3D flattened to 2D, 3: 3D pyramid, 4: proposed (tetrahedral G0)
+    MLP_NUM_DTYPE: int = 32
+    NUM_EPOCHS: int = 1000
+    UNIFORM_DISTRIBUTION_RATE: float = 0.05
+    IMAGE_3D_SIZE: int = 64
+    IMAGE_SIZE: int = 512
+    IMAGE_DIMENSION: int = 2
+    MAX_MIP_LEVEL: int = 9
+    IMAGE_BITS: int = 8
+    OUTPUT_BITS: int = 8
+    FEATURE_PYRAMID_CHANNELS: int = 12
+    PE_CHANNELS: int = 6
+    FP_BITS: int = 8
+    HIDDEN_LAYER_CHANNELS: int = 64
+    CROP_MIP_LEVEL: int = 8
+    NUM_CROPS: int = 8
+    INTERVAL_PRINT: int = 100
+    INTERVAL_SAVE_MODEL: int = 100000
+    TF_NO_MIP: bool = True
+    TF_USE_TRI_PE: bool = True
+    TF_TRAIN_MODEL: bool = True
+    TF_SHOW_RESULT: bool = False
+    TF_PRINT_LOG: bool = True
+    TF_PRINT_PSNR: bool = True
+    TF_WRITE_TIME: bool = True
+    TF_WRITE_PSNR: bool = True
+
+    def __post_init__(self):
+        if self.TF_NO_MIP:
+            self.MAX_MIP_LEVEL = 0                                   # var2.py:112-113
+
+    @classmethod
+    def from_argv(cls, argv: Sequence[str]) -> "Settings":
+        kw = {}
+        names = {f.name: f.type for f in fields(cls)}
+        for arg in argv:
+            for name, typ in names.items():
+                if arg.startswith(name + "="):
+                    t = typ if isinstance(typ, str) else typ.__name__
+                    kw[name] = judge_value(arg, t, name)
+        return cls(**kw)
+
+    @property
+    def DEVICE(self):
+        return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    @property
+    def FEATURE_PYRAMID_SIZE(self):
+        return self.IMAGE_SIZE // 4                                   # var2.py:107
+
+    @property
+    def FP_DIMENSION(self):
+        return 2 if self.COMPRESSION_METHOD == 2 else self.IMAGE_DIMENSION
+
+    @property
+    def DECODER_INPUT_CHANNELS(self):
+        C, P, D = self.FEATURE_PYRAMID_CHANNELS, self.PE_CHANNELS, self.FP_DIMENSION
+        if self.COMPRESSION_METHOD == 4:
+            return C * (pow(2, 2) + 1) + P * D + 1                    # var2.py:117-118
+        return C * (pow(2, D) + 1) + P * D + 1
+
+    @property
+    def CROP_SIZE(self):
+        return pow(2, self.CROP_MIP_LEVEL)
+
+    @property
+    def MLP_DTYPE(self):
+        return bits2dtype_torch(self.MLP_NUM_DTYPE, "float")
