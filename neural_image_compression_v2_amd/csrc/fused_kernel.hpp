@@ -60,7 +60,13 @@ struct Lds {
     static constexpr int OFF_B2 = OFF_W3 + 4 * LD2;           // W3 rows 0..2 + one zero row (k padding of dA2)
     static constexpr int OFF_B3 = OFF_B2 + kH;
     static constexpr int OFF_SCR = OFF_B3 + 16;
-    static constexpr int SCR_PER_WAVE = 128 * LDT;            // SA (64 rows) + SB (64 rows)
+    // wave-private "node box": the grid nodes one 32-sample tile can touch when step_number <= 1/2, per grid
+    // (2D tile 4 x 8: G0 <= 4 x 6 nodes, G1 <= 3 x 4;  3D tile 2 x 4 x 4: G0 <= 3 x 4 x 4, G1 <= 3 x 3 x 3)
+    static constexpr int BX0 = L::DIM == 2 ? 4 : 3, BY0 = L::DIM == 2 ? 6 : 4, BZ0 = L::DIM == 2 ? 1 : 4;
+    static constexpr int BX1 = 3, BY1 = L::DIM == 2 ? 4 : 3, BZ1 = L::DIM == 2 ? 1 : 3;
+    static constexpr int NB0 = BX0 * BY0 * BZ0, NB1 = BX1 * BY1 * BZ1;
+    static constexpr int BOX = ((NB0 + NB1) * kC + 3) / 4 * 4;
+    static constexpr int SCR_PER_WAVE = 128 * LDT + BOX;      // SA (64 rows) + SB (64 rows) + node boxes
     static constexpr int TOTAL_INFER = OFF_SCR;
     static constexpr int TOTAL_TRAIN = OFF_SCR + 4 * SCR_PER_WAVE;
     static constexpr int NACC = 2 * KT + 4;                   // MFMA accumulator tiles: dW1 [2][KT], dW2 [2][2]
@@ -92,12 +98,15 @@ __device__ __forceinline__ lds_f* opaque(lds_f* p) {
     return p;
 }
 __device__ __forceinline__ f32x4 ld4(lds_cf* p) { return *reinterpret_cast<lds_cf4*>(p); }
+// ds_add_f32 (no return): wave-private accumulation, workgroup scope is plenty
+__device__ __forceinline__ void lds_add(lds_f* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __host__ __device__ constexpr int ROWC(int r) { return (r & 3) + 8 * (r >> 2); }   // ROW(r,h) = ROWC(r) + 4h
 
 // what the scatter needs to recompute a slot's grid address
 struct EncCtx {
     int64_t off0, off1;     // element offsets of corner (0,0,0) in G0 / G1 (channel 0)
     float kx, ky, kz;       // G1 interpolation fractions
+    int c0[3], c1[3];       // (clamped) cell coordinates of the sample in G0 / G1
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -175,6 +184,8 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, int crop, int
     const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2), z1 = D == 3 ? clampi(az.i1, 0, p.g1.nz - 2) : 0;
     cx.off0 = p.g0.at(x0, y0, z0);
     cx.off1 = p.g1.at(x1, y1, z1);
+    cx.c0[0] = x0; cx.c0[1] = y0; cx.c0[2] = z0;
+    cx.c1[0] = x1; cx.c1[1] = y1; cx.c1[2] = z1;
     cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = az.k1;
     constexpr int NG0 = L::K0 / 2 * kC;             // G0 slots per half
     // --- G0 raw corners
@@ -214,7 +225,7 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, int crop, int
                 const int k = r >> 1;
                 const float dv = k == 0 ? pdiv[0] : (k == 1 ? pdiv[1] : pdiv[2]);
                 float sv, cv;
-                sincos_cw(__fmul_rn(c, dv), sv, cv);
+                sincos_cw(mul_rn(c, dv), sv, cv);
                 v = (r & 1) ? cv : sv;
             }
             if (pe0) v0 = v;
@@ -261,7 +272,8 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
     }
 }
 
-// scatter of the grid-slot gradients (index_put_(accumulate=True) of the gathers' backward)
+// scatter of the grid-slot gradients (index_put_(accumulate=True) of the gathers' backward), direct form: one global
+// fp32 atomic per lane and slot.  Used when step_number >= 1 (every sample has its own cell: nothing to merge).
 template <class L, int NT>
 __device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const EncCtx& cx, int h, const f32x16 (&dxacc)[NT]) {
     constexpr int D = L::DIM;
@@ -288,6 +300,73 @@ __device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const E
             atomicAdd(pc + p.g1.at(dx, dy, dz), gsum * w[q]);
         }
     }
+}
+
+// Tile-local form for step_number <= 1/2, where 4^D (G0) / 8^D (G1) samples share a cell at mip 0: every lane adds its
+// slot gradients into a wave-private LDS box of the nodes the tile can touch (ds_add_f32; same-address lanes serialise
+// inside the LDS, ~100x cheaper than at the memory-side atomic units), then the wave flushes each touched node with ONE
+// global atomic.  Per 32-sample tile this replaces 96 wave-atomics whose lanes collide on a handful of addresses by ~8
+// wave-atomics with a distinct address per lane.  (bx, by, bz) = node coordinates of the box origin, wave-uniform.
+template <class L, int NT>
+__device__ __forceinline__ void scatter_grid_grads_box(const FusedParams& p, const EncCtx& cx, int h, int lane, bool valid, lds_f* box,
+                                                       const int (&b0)[3], const int (&b1)[3], const int (&l0)[3], const int (&l1)[3],
+                                                       const f32x16 (&dxacc)[NT]) {
+    using S = Lds<L>;
+    constexpr int D = L::DIM;
+    constexpr int NG0 = L::K0 / 2 * kC;
+    lds_f* const box0 = box;
+    lds_f* const box1 = box + S::NB0 * kC;
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < NG0; ++s) {
+            int dx, dy, dz;
+            g0_corner<L>(s / kC, h, dx, dy, dz);
+            const int node = ((l0[2] + dz) * S::BY0 + (l0[1] + dy)) * S::BX0 + l0[0] + dx;
+            lds_add(box0 + (s % kC) * S::NB0 + node, dxacc[s >> 4][s & 15]);
+        }
+        constexpr int K1 = D == 2 ? 4 : 8;
+        const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+#pragma unroll
+        for (int cc = 0; cc < kC / 2; ++cc) {
+            const int s = NG0 + cc;
+            const float gsum = dxacc[s >> 4][s & 15];
+#pragma unroll
+            for (int q = 0; q < K1; ++q) {
+                const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+                const int node = ((l1[2] + dz) * S::BY1 + (l1[1] + dy)) * S::BX1 + l1[0] + dx;
+                lds_add(box1 + (kC / 2 * h + cc) * S::NB1 + node, gsum * g1_corner_factor<D>(gf, q));
+            }
+        }
+    }
+    wave_lds_fence();
+    // flush + re-zero
+#pragma unroll
+    for (int i = 0; i < (S::NB0 * kC + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < S::NB0 * kC) {
+            const float v = box0[idx];
+            if (v != 0.f) {
+                const int c = idx / S::NB0, node = idx - c * S::NB0;
+                const int x = b0[0] + node % S::BX0, y = b0[1] + (node / S::BX0) % S::BY0, z = b0[2] + node / (S::BX0 * S::BY0);
+                box0[idx] = 0.f;
+                if (x < p.g0.nx && y < p.g0.ny && z < p.g0.nz) atomicAdd(p.g0_grad + (int64_t)c * p.g0.plane + p.g0.at(x, y, z), v);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (S::NB1 * kC + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < S::NB1 * kC) {
+            const float v = box1[idx];
+            if (v != 0.f) {
+                const int c = idx / S::NB1, node = idx - c * S::NB1;
+                const int x = b1[0] + node % S::BX1, y = b1[1] + (node / S::BX1) % S::BY1, z = b1[2] + node / (S::BX1 * S::BY1);
+                box1[idx] = 0.f;
+                if (x < p.g1.nx && y < p.g1.ny && z < p.g1.nz) atomicAdd(p.g1_grad + (int64_t)c * p.g1.plane + p.g1.at(x, y, z), v);
+            }
+        }
+    }
+    wave_lds_fence();
 }
 
 // =====================================================================================================
@@ -661,7 +740,30 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             if (SRC == SRC_ENCODE) {
-                if (valid) scatter_grid_grads<L, NGT>(p, cx, h, dxacc);
+                if (p.d.reserved & 1) {
+                    // debug / profiling only: skip the grid-gradient scatter (results are then incomplete)
+                } else if (p.d.log2_step <= -1) {
+                    // box origin = cell of the tile's first sample (wave-uniform); the lane's offset inside the box
+                    int b0[3], b1[3], l0[3], l1[3];
+                    const int tq[3] = {ix - ix % L::TX, iy - iy % L::TY, iz - iz % L::TZ};       // tile origin (clamped lanes included)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        if (a < L::DIM) {
+                            const Axis t0 = axis_coords(p.origins[crop * L::DIM + a] + tq[a], p.d.log2_step);
+                            const int n0 = a == 0 ? p.g0.nx : (a == 1 ? p.g0.ny : p.g0.nz), n1 = a == 0 ? p.g1.nx : (a == 1 ? p.g1.ny : p.g1.nz);
+                            b0[a] = clampi(t0.i0, 0, n0 - 2);
+                            b1[a] = clampi(t0.i1, 0, n1 - 2);
+                        } else {
+                            b0[a] = b1[a] = 0;
+                        }
+                        constexpr int B0[3] = {S::BX0, S::BY0, S::BZ0}, B1[3] = {S::BX1, S::BY1, S::BZ1};
+                        l0[a] = a < L::DIM ? clampi(cx.c0[a] - b0[a], 0, B0[a] - 2) : 0;
+                        l1[a] = a < L::DIM ? clampi(cx.c1[a] - b1[a], 0, B1[a] - 2) : 0;
+                    }
+                    scatter_grid_grads_box<L, NGT>(p, cx, h, lane, valid, SB + 64 * LDT, b0, b1, l0, l1, dxacc);
+                } else if (valid) {
+                    scatter_grid_grads<L, NGT>(p, cx, h, dxacc);
+                }
             } else if (valid) {
                 float* row = p.dx + n * L::CIN;
 #pragma unroll
@@ -710,8 +812,14 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
     constexpr int KT = S::KT;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= S::NACC * 1024 + S::TAIL) return;
-    float acc = 0.f;
-    for (int w = 0; w < n_waves; ++w) acc += partials[(int64_t)w * S::REC + gid];
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
+    int w = 0;
+    for (; w + 8 <= n_waves; w += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] += partials[(int64_t)(w + j) * S::REC + gid];
+    }
+    for (; w < n_waves; ++w) part[0] += partials[(int64_t)w * S::REC + gid];
+    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     if (gid < S::NACC * 1024) {
         const int a = gid >> 10, r = (gid >> 6) & 15, lane = gid & 63;
         const int row = ROW(r, lane >> 5), col = lane & 31;

@@ -37,8 +37,16 @@ __device__ __forceinline__ Axis axis_coords(int q, int e) {
 // products / sums that must not be contracted into FMAs: the reference evaluates
 // ((g * wx) * wy) (* wz) and adds the corners left to right in fp32 (fp_def.py:141-144, 176-183;
 // image_compression.py:95), and the encode is held to bit-exactness against it.
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+// (HIP's __fmul_rn / __fadd_rn are plain operators and DO get contracted under the default -ffp-contract=fast;
+//  the pragma clears the 'contract' flag on these instructions, which fast-honor-pragmas respects.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Positional encodings
@@ -86,7 +94,7 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
 }
 // row r of the sinusoidal block: even -> sin(c * div[r/2]), odd -> cos (utils.py:198-208)
 __device__ __forceinline__ float sin_pe_row(float c, int r, const float* div) {
-    const float a = __fmul_rn(c, div[r >> 1]);
+    const float a = mul_rn(c, div[r >> 1]);
     float sv, cv;
     sincos_cw(a, sv, cv);
     return (r & 1) ? cv : sv;

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass, field, replace
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -114,6 +115,7 @@ class PathGeometry:
         d.philox_offset = int(self.philox_offset) & 0xFFFFFFFFFFFFFFFF
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
+        d.reserved = int(os.environ.get("NIC_DEBUG_FLAGS", "0"))     # profiling experiments only (bit 0: skip the grid-gradient scatter)
         return d
 
 
@@ -258,7 +260,7 @@ def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor):
 
 def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: torch.Tensor,
                            noise: Optional[torch.Tensor] = None, want_y: bool = False,
-                           flat: Optional[torch.Tensor] = None) -> StepOutput:
+                           flat: Optional[torch.Tensor] = None, events=None) -> StepOutput:
     """One training step's forward + MSE + backward in one launch (+ the fixed-order partial reduction):
     image_compression.py:239-265.  Gradients are returned, not accumulated into .grad."""
     g0 = _lib.require_cuda_f32(g0.detach(), "G0")
@@ -292,10 +294,14 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     ws = _lib.workspace(dev, ws_bytes)
     m = _mlp_struct(params)
     gs = _grads_struct(gm)
+    if events is not None:                   # (start, end) torch.cuda.Event pair recorded on the launch stream
+        events[0].record(torch.cuda.current_stream(dev))
     _lib.check(lib.nic_fused_forward_backward(
         ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
         _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(target), _lib.ptr(y), _lib.ptr(views[0]),
         _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_forward_backward")
+    if events is not None:
+        events[1].record(torch.cuda.current_stream(dev))
     return StepOutput(views[0][0], y, gg0, gg1, gm, flat)
 
 
