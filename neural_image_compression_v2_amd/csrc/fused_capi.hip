@@ -127,11 +127,12 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     p.target = target; p.dy = dy; p.y = y;
     p.partials = (float*)workspace;
     const int grid = grid_for(p.n_tiles, 1);
-    if (workspace_bytes < (size_t)grid * 4 * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
+    const int n_rec = grid * 4 / fi.waves_per_rec;
+    if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     rc = launch(layout, SRC_ENCODE, target ? MODE_TRAIN_MSE : MODE_TRAIN_DY, p, grid, s);
     if (rc) return rc;
-    return reduce(layout, p.partials, grid * 4, *grads, target ? loss : nullptr, d->loss_scale, s);
+    return reduce(layout, p.partials, n_rec, *grads, target ? loss : nullptr, d->loss_scale, s);
 }
 
 }  // namespace
@@ -206,11 +207,12 @@ int nic_decoder_backward(const nic_mlp* mlp, const float* x, const float* dy, in
     p.x = x; p.dy = dy; p.dx = dx; p.n_total = n; p.n_tiles = (n + 31) / 32;
     p.partials = (float*)workspace;
     const int grid = grid_for(p.n_tiles, 1);
-    if (workspace_bytes < (size_t)grid * 4 * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
+    const int n_rec = grid * 4 / fi.waves_per_rec;
+    if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int rc = launch(layout, SRC_MEMORY, MODE_TRAIN_DY, p, grid, s);
     if (rc) return rc;
-    return reduce(layout, p.partials, grid * 4, *grads, nullptr, 0.f, s);
+    return reduce(layout, p.partials, n_rec, *grads, nullptr, 0.f, s);
 }
 
 }  // extern "C"

@@ -54,6 +54,8 @@ struct Lds {
     static constexpr int LD1 = KPAD + 4;                      // row strides are 4 * odd: conflict-free b128 rows
     static constexpr int LD2 = kH + 4;
     static constexpr int LDT = 36;                            // transposed scratch: 32 samples + 4
+    static constexpr int NACC = 2 * KT + 4;                   // MFMA accumulator tiles: dW1 [2][KT], dW2 [2][2]
+    static constexpr int TAIL = 64 + 192 + 4;                 // db2[64], dW3[3][64], db3[3], loss
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_W2 = OFF_W1 + kH * LD1;
     static constexpr int OFF_W3 = OFF_W2 + kH * LD2;
@@ -69,9 +71,14 @@ struct Lds {
     static constexpr int SCR_PER_WAVE = 128 * LDT + BOX;      // SA (64 rows) + SB (64 rows) + node boxes
     static constexpr int TOTAL_INFER = OFF_SCR;
     static constexpr int TOTAL_TRAIN = OFF_SCR + 4 * SCR_PER_WAVE;
-    static constexpr int NACC = 2 * KT + 4;                   // MFMA accumulator tiles: dW1 [2][KT], dW2 [2][2]
-    static constexpr int TAIL = 64 + 192 + 4;                 // db2[64], dW3[3][64], db3[3], loss
-    static constexpr int REC = NACC * 1024 + 320;             // floats per wave in the workspace
+    // Decoder-gradient bookkeeping.  The 4 waves of a workgroup split OWNERSHIP of the dW output tiles: each wave
+    // contracts its tiles over the transposed operands of all 4 waves (K = 128 samples per round), so a wave carries
+    // 3-4 accumulator tiles (48-64 registers) through the launch instead of all NACC (160-192).  The odd col-tile of dW1
+    // (KT odd: 2D and method 4) is contracted by every wave over its own samples only ("partial" tiles, summed later).
+    static constexpr int KTF = KT & ~1;                       // dW1 col tiles handled in cross-wave chunks of two
+    static constexpr int PART = KT & 1;
+    static constexpr int NSLOT_REC = NACC + (PART ? 8 : 0);   // + [4 waves][2 row tiles] partial tiles
+    static constexpr int REC = NSLOT_REC * 1024 + 4 * 320;    // floats per WORKGROUP record; tails per wave: db2, dW3, db3, loss
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -84,6 +91,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier for LDS hand-offs.  NOT __syncthreads(): that also drains vmcnt, i.e. waits for the previous tile's
+// fire-and-forget gradient atomics (thousands of cycles); only this wave's LDS traffic has to be complete here.
+__device__ __forceinline__ void wg_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // Makes a per-lane LDS base pointer opaque to the optimiser at this point of the tile loop: everything
@@ -104,7 +119,7 @@ __host__ __device__ constexpr int ROWC(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // what the scatter needs to recompute a slot's grid address
 struct EncCtx {
-    int64_t off0, off1;     // element offsets of corner (0,0,0) in G0 / G1 (channel 0)
+    uint32_t off0, off1;    // element offsets of corner (0,0,0) in G0 / G1 (channel 0); a channel plane is < 2^32 elements
     float kx, ky, kz;       // G1 interpolation fractions
     int c0[3], c1[3];       // (clamped) cell coordinates of the sample in G0 / G1
 };
@@ -182,26 +197,53 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, int crop, int
     // memory safety: a corner index never leaves the grid, whatever the origins hold
     const int x0 = clampi(ax.i0, 0, p.g0.nx - 2), y0 = clampi(ay.i0, 0, p.g0.ny - 2), z0 = D == 3 ? clampi(az.i0, 0, p.g0.nz - 2) : 0;
     const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2), z1 = D == 3 ? clampi(az.i1, 0, p.g1.nz - 2) : 0;
-    cx.off0 = p.g0.at(x0, y0, z0);
-    cx.off1 = p.g1.at(x1, y1, z1);
+    cx.off0 = (uint32_t)p.g0.at(x0, y0, z0);
+    cx.off1 = (uint32_t)p.g1.at(x1, y1, z1);
     cx.c0[0] = x0; cx.c0[1] = y0; cx.c0[2] = z0;
     cx.c1[0] = x1; cx.c1[1] = y1; cx.c1[2] = z1;
     cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = az.k1;
     constexpr int NG0 = L::K0 / 2 * kC;             // G0 slots per half
-    // --- G0 raw corners
+    // --- G0 raw corners.  Address = (uniform channel-plane base in SGPRs) + (one 32-bit lane offset per corner): the 12
+    // channel loads of a corner share ONE offset register (96 address registers otherwise)
 #pragma unroll
-    for (int s = 0; s < NG0; ++s) {
+    for (int e = 0; e < NG0 / kC; ++e) {
         int dx, dy, dz;
-        g0_corner<L>(s / kC, h, dx, dy, dz);
-        xs[s] = p.g0.p[cx.off0 + p.g0.at(dx, dy, dz) + (int64_t)(s % kC) * p.g0.plane];
-    }
-    // --- G1: channels (kC/2)*h + cc
-    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+        g0_corner<L>(e, h, dx, dy, dz);
+        const uint32_t voff = cx.off0 + (uint32_t)p.g0.at(dx, dy, dz);
 #pragma unroll
-    for (int cc = 0; cc < kC / 2; ++cc) {
-        const float* pc = p.g1.p + cx.off1 + (int64_t)(kC / 2 * h + cc) * p.g1.plane;
-        xs[NG0 + cc] = g1_blend<D>(pc, p.g1, gf);
+        for (int c = 0; c < kC; ++c) {
+            const float* plane = p.g0.p + (int64_t)c * p.g0.plane;           // wave-uniform
+            xs[e * kC + c] = plane[voff];
+        }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- G1: channels (kC/2)*h + cc, blended with the reference's factor order
+    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+    {
+        constexpr int K1 = D == 2 ? 4 : 8;
+        uint32_t voff[K1];
+#pragma unroll
+        for (int q = 0; q < K1; ++q) {
+            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+            voff[q] = cx.off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(kC / 2 * h) * (uint32_t)p.g1.plane;
+        }
+#pragma unroll
+        for (int cc = 0; cc < kC / 2; ++cc) {
+            const float* plane = p.g1.p + (int64_t)cc * p.g1.plane;          // wave-uniform; the lane-half part is in voff
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < K1; ++q) {
+                const uint32_t b = (gf.bits >> (3 * q)) & 7u;
+                float v = plane[voff[q]];
+                v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+                v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+                if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
+                sum = q == 0 ? v : add_rn(sum, v);
+            }
+            xs[NG0 + cc] = sum;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // --- remaining slots: PE rows, LOD, the constant one, zero padding.  The channel of a slot is affine
     // in h, so its kind is known at compile time per half; only PE row / axis are lane-half dependent.
     float pdiv[kP / 2];
@@ -255,20 +297,19 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
         const U4 b = noise_block(ns, sample_global, NG0 / 8 * h + j);
 #pragma unroll
         for (int t = 0; t < 8; ++t) xs[8 * j + t] += noise_from_block(ns, b, t);
+        __builtin_amdgcn_sched_barrier(0);       // one Philox block in flight at a time: bounds the live registers
     }
     constexpr int RB0 = L::K0 * kC / 8;              // first block of the non-G0 channels
     static_assert((L::CIN - 1) / 8 - RB0 <= 3, "rest channels span at most 4 blocks");
-    U4 rb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = noise_block(ns, sample_global, RB0 + j);
+    for (int j = 0; j < 4; ++j) {
+        const U4 b = noise_block(ns, sample_global, RB0 + j);
 #pragma unroll
-    for (int s = NG0; s < L::NSLOT; ++s) {
-        const int ch = L::slot_channel(s, h);
-        if (ch >= 0) {
-            const int j = (ch >> 3) - RB0;
-            const U4 b = j == 0 ? rb[0] : (j == 1 ? rb[1] : (j == 2 ? rb[2] : rb[3]));
-            xs[s] += noise_from_block(ns, b, ch);
+        for (int s = NG0; s < L::NSLOT; ++s) {
+            const int ch = L::slot_channel(s, h);
+            if (ch >= 0 && (ch >> 3) - RB0 == j) xs[s] += noise_from_block(ns, b, ch);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -282,7 +323,7 @@ __device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const E
     for (int s = 0; s < NG0; ++s) {
         int dx, dy, dz;
         g0_corner<L>(s / kC, h, dx, dy, dz);
-        atomicAdd(p.g0_grad + cx.off0 + p.g0.at(dx, dy, dz) + (int64_t)(s % kC) * p.g0.plane, dxacc[s >> 4][s & 15]);
+        atomicAdd(p.g0_grad + (int64_t)(s % kC) * p.g0.plane + (cx.off0 + (uint32_t)p.g0.at(dx, dy, dz)), dxacc[s >> 4][s & 15]);
     }
     constexpr int K1 = D == 2 ? 4 : 8;
     const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
@@ -293,7 +334,7 @@ __device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const E
     for (int cc = 0; cc < kC / 2; ++cc) {
         const int s = NG0 + cc;
         const float gsum = dxacc[s >> 4][s & 15];
-        float* pc = p.g1_grad + cx.off1 + (int64_t)(kC / 2 * h + cc) * p.g1.plane;
+        float* pc = p.g1_grad + (int64_t)(kC / 2 * h + cc) * p.g1.plane + cx.off1;
 #pragma unroll
         for (int q = 0; q < K1; ++q) {
             const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
@@ -409,34 +450,39 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     if (tid < kH) B2s[tid] = p.b[1][tid];
     if (tid < 16) B3s[tid] = tid < 3 ? p.b[2][tid] : 0.f;
     if (TRAIN)
-        for (int idx = tid; idx < 4 * S::SCR_PER_WAVE; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
+        for (int idx = tid; idx < S::TOTAL_TRAIN - S::OFF_SCR; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
     __syncthreads();
+    lds_f* const SCR0 = sm + S::OFF_SCR;                        // wave 0's scratch; wave w's is SCR_PER_WAVE * w further
 
     lds_f* const SA = sm + S::OFF_SCR + (TRAIN ? wave * S::SCR_PER_WAVE : 0);
     lds_f* const SB = SA + 64 * LDT;
 
-    // ---------------- launch-lifetime accumulators (training)
-    f32x16 accW1[2][KT], accW2[2][2];
+    // ---------------- launch-lifetime accumulators (training): the dW tiles this wave OWNS
+    constexpr int NCH = S::KTF / 2;                             // cross-wave dW1 chunks (2 col tiles each)
+    f32x16 accW2o = f32x16(0.f);                                // dW2 tile (to = wave >> 1, tk = wave & 1)
+    f32x16 accW1o[NCH > 0 ? NCH : 1];                           // dW1 tiles (to = wave & 1, tk = 2c + (wave >> 1))
+    f32x16 accW1p[2];                                           // partial dW1 tiles (to = 0, 1; tk = KT - 1), own samples
+#pragma unroll
+    for (int c = 0; c < (NCH > 0 ? NCH : 1); ++c) accW1o[c] = f32x16(0.f);
+    accW1p[0] = accW1p[1] = f32x16(0.f);
     float accW3[3] = {0.f, 0.f, 0.f};     // dW3[c][k = lane]
     float accB2 = 0.f;                    // db2[o = lane]
     float accB3[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
-    if (TRAIN) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int b = 0; b < KT; ++b) accW1[a][b] = f32x16(0.f);
-            accW2[a][0] = accW2[a][1] = f32x16(0.f);
-        }
-    }
+    const int to2 = wave >> 1, tk2 = wave & 1;                  // ownership
+    const int to1 = wave & 1, tk1 = wave >> 1;
 
-    // ---------------- XCD-aware persistent tile walk
+    // ---------------- XCD-aware persistent walk, in workgroup-synchronous rounds of 4 tiles (one per wave)
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
     const int64_t chunk = (p.n_tiles + 7) >> 3;
     const int64_t t_begin = xcd * chunk;
     const int64_t t_end = t_begin + chunk < p.n_tiles ? t_begin + chunk : p.n_tiles;
     const int lstride = nb8 * 4;
 
-    for (int64_t tile = t_begin + (blockIdx.x >> 3) * 4 + wave; tile < t_end; tile += lstride) {
+    for (int64_t base = t_begin + (int64_t)(blockIdx.x >> 3) * 4; base < t_end; base += lstride) {
+        // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
+        // last tile with every lane masked, which contributes exact zeros everywhere
+        const bool tile_ok = base + wave < t_end;
+        const int64_t tile = tile_ok ? base + wave : t_end - 1;
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         lds_cf* const w1_row = opaque(W1s + pl * LD1 + 4 * h);      // A rows of layer 1 (b128 along k)
         lds_cf* const w2_row = opaque(W2s + pl * LD2 + 4 * h);
@@ -472,14 +518,14 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 ix = tx * L::TX + lx; iy = ty * L::TY + ly; iz = tz * L::TZ + lz;
             }
             const int ez = L::DIM == 3 ? p.d.extent[2] : 1;
-            valid = ix < p.d.extent[0] && iy < p.d.extent[1] && iz < ez;
+            valid = tile_ok && ix < p.d.extent[0] && iy < p.d.extent[1] && iz < ez;
             ix = ix < p.d.extent[0] ? ix : p.d.extent[0] - 1;
             iy = iy < p.d.extent[1] ? iy : p.d.extent[1] - 1;
             iz = iz < ez ? iz : ez - 1;
             n = (int64_t)crop * p.n_per_crop + ((int64_t)ix * p.d.extent[1] + iy) * ez + iz;
         } else {
             n = tile * 32 + pl;
-            valid = n < p.n_total;
+            valid = tile_ok && n < p.n_total;
             n = valid ? n : p.n_total - 1;
         }
 
@@ -644,7 +690,8 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---------- dW2[o][k] += sum_s dZ2[o][s] A1[k][s]
+        // ---------- dW2[o][k] += sum_s dZ2[o][s] A1[k][s]: every wave publishes its transposed operands, then contracts the
+        // ONE tile it owns over the samples of all four waves
         wave_lds_fence();
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -655,26 +702,27 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             }
         wave_lds_fence();
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {                                  // db2[o = lane] += sum_s dZ2[o][s]
+        for (int g = 0; g < 8; ++g) {                                  // db2[o = lane] += sum_s dZ2[o][s]   (own samples)
             const f32x4 zv = ld4(&sa_lane[4 * g]);
             accB2 += (zv[0] + zv[1]) + (zv[2] + zv[3]);
         }
+        wg_lds_barrier();
+        {
+            lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to2 * LDT);
+            lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk2 * LDT);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 a[2], b[2];
+            for (int src = 0; src < 4; ++src) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = ld4(&sa_rd[32 * t * LDT + 4 * g]);
-                b[t] = ld4(&sb_rd[32 * t * LDT + 4 * g]);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = ld4(&sa_o[src * S::SCR_PER_WAVE + 4 * g]);
+                    const f32x4 b = ld4(&sb_o[src * S::SCR_PER_WAVE + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accW2o = mfma32(a[j], b[j], accW2o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int to = 0; to < 2; ++to)
-#pragma unroll
-                for (int tk = 0; tk < 2; ++tk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) accW2[to][tk] = mfma32(a[to][j], b[tk][j], accW2[to][tk]);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        wg_lds_barrier();                                              // everyone is done reading before the operands are replaced
         __builtin_amdgcn_sched_barrier(0);
         // ---------- dA1 = W2^T dZ2, dZ1 = dA1 * gelu'(Z1)
         f32x16 dz1[2];
@@ -694,33 +742,46 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---------- dW1[o][rho] += sum_s dZ1[o][s] X[rho][s]   (X staged two 32-row tiles at a time)
-        wave_lds_fence();
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sa_st[(32 * t + ROWC(r)) * LDT] = dz1[t][r];
 #pragma unroll
         for (int c2 = 0; c2 < (KT + 1) / 2; ++c2) {
-            if (c2 > 0) wave_lds_fence();
 #pragma unroll
             for (int s = 32 * c2; s < 32 * c2 + 32 && s < L::NSLOT; ++s) sb_st[(32 * ((s >> 4) & 1) + ROWC(s & 15)) * LDT] = xs[s];
-            wave_lds_fence();
+            if (c2 < NCH) {
+                // full chunk: owned tile (to1, 2 c2 + tk1) over the four waves' samples
+                wg_lds_barrier();
+                lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to1 * LDT);
+                lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk1 * LDT);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a[2];
+                for (int src = 0; src < 4; ++src) {
 #pragma unroll
-                for (int to = 0; to < 2; ++to) a[to] = ld4(&sa_rd[32 * to * LDT + 4 * g]);
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a = ld4(&sa_o[src * S::SCR_PER_WAVE + 4 * g]);
+                        const f32x4 b = ld4(&sb_o[src * S::SCR_PER_WAVE + 4 * g]);
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    if (2 * c2 + tt < KT) {
-                        const f32x4 b = ld4(&sb_rd[32 * tt * LDT + 4 * g]);
-#pragma unroll
-                        for (int to = 0; to < 2; ++to)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) accW1[to][2 * c2 + tt] = mfma32(a[to][j], b[j], accW1[to][2 * c2 + tt]);
+                        for (int j = 0; j < 4; ++j) accW1o[c2 < NCH ? c2 : 0] = mfma32(a[j], b[j], accW1o[c2 < NCH ? c2 : 0]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                wg_lds_barrier();
+            } else {
+                // odd last col tile: both row tiles over this wave's own samples
+                wave_lds_fence();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = ld4(&sb_rd[4 * g]);
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        const f32x4 a = ld4(&sa_rd[32 * to * LDT + 4 * g]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accW1p[to] = mfma32(a[j], b[j], accW1p[to]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wave_lds_fence();
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -776,22 +837,26 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     }  // tile loop
 
     if (!TRAIN) return;
-    // ---------------- flush the accumulators of this wave: [NACC][16 regs][64 lanes], then db2[64], db3[3], loss
-    float* rec = p.partials + ((int64_t)blockIdx.x * 4 + wave) * S::REC;
-    int a = 0;
+    // ---------------- flush: ONE record per workgroup; every wave writes the tiles it owns, its partial tiles and its tail
+    float* rec = p.partials + (int64_t)blockIdx.x * S::REC;
+    {
+        const int a2 = 2 * KT + 2 * to2 + tk2;
 #pragma unroll
-    for (int to = 0; to < 2; ++to)
+        for (int r = 0; r < 16; ++r) rec[(a2 * 16 + r) * 64 + lane] = accW2o[r];
 #pragma unroll
-        for (int tk = 0; tk < KT; ++tk, ++a)
+        for (int c = 0; c < NCH; ++c) {
+            const int a1i = to1 * KT + 2 * c + tk1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rec[(a * 16 + r) * 64 + lane] = accW1[to][tk][r];
+            for (int r = 0; r < 16; ++r) rec[(a1i * 16 + r) * 64 + lane] = accW1o[c][r];
+        }
+        if (S::PART) {
 #pragma unroll
-    for (int to = 0; to < 2; ++to)
+            for (int to = 0; to < 2; ++to)
 #pragma unroll
-        for (int tk = 0; tk < 2; ++tk, ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rec[(a * 16 + r) * 64 + lane] = accW2[to][tk][r];
-    float* tail = rec + S::NACC * 1024;
+                for (int r = 0; r < 16; ++r) rec[((S::NACC + 2 * wave + to) * 16 + r) * 64 + lane] = accW1p[to][r];
+        }
+    }
+    float* tail = rec + S::NSLOT_REC * 1024 + wave * 320;
     tail[lane] = accB2;
 #pragma unroll
     for (int c = 0; c < 3; ++c) tail[64 + 64 * c + lane] = accW3[c];
@@ -807,18 +872,31 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 // =====================================================================================================
 // Fixed-order reduction of the per-wave records into the decoder gradients (nn.Linear layouts) and loss.
 template <class L>
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves /* records */, nic_mlp_grads g, float* loss, float loss_scale) {
     using S = Lds<L>;
     constexpr int KT = S::KT;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= S::NACC * 1024 + S::TAIL) return;
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
-    int w = 0;
-    for (; w + 8 <= n_waves; w += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) part[j] += partials[(int64_t)(w + j) * S::REC + gid];
+    // which floats of a record feed output gid: one slot, or (partial dW1 tiles, tails) one slot per wave
+    int nsrc = 1, off0 = gid, stride = 0;
+    if (gid < S::NACC * 1024) {
+        const int a = gid >> 10;
+        if (S::PART && a < 2 * KT && a % KT == KT - 1) {          // dW1 tile (to, KT-1): 4 per-wave partials
+            nsrc = 4; off0 = (S::NACC + a / KT) * 1024 + (gid & 1023); stride = 2 * 1024;
+        }
+    } else {
+        nsrc = 4; off0 = S::NSLOT_REC * 1024 + (gid - S::NACC * 1024); stride = 320;
     }
-    for (; w < n_waves; ++w) part[0] += partials[(int64_t)w * S::REC + gid];
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
+    for (int k = 0; k < nsrc; ++k) {
+        const float* src = partials + off0 + k * stride;
+        int w = 0;
+        for (; w + 8 <= n_waves; w += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
+        }
+        for (; w < n_waves; ++w) part[0] += src[(int64_t)w * S::REC];
+    }
     const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     if (gid < S::NACC * 1024) {
         const int a = gid >> 10, r = (gid >> 6) & 15, lane = gid & 63;

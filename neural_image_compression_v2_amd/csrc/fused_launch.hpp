@@ -6,7 +6,7 @@
 namespace nic {
 
 struct FusedInfo {
-    int nacc, rec, tx, ty, tz, cin;
+    int nacc, rec, tx, ty, tz, cin, waves_per_rec;
 };
 
 template <int METHOD>
@@ -20,7 +20,7 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
     template <>                                                                                                          \
     FusedInfo fused_info<METHOD>() {                                                                                     \
         using L = Layout<METHOD>;                                                                                        \
-        return FusedInfo{Lds<L>::NACC, Lds<L>::REC, L::TX, L::TY, L::TZ, L::CIN};                                        \
+        return FusedInfo{Lds<L>::NACC, Lds<L>::REC, L::TX, L::TY, L::TZ, L::CIN, 4};                                        \
     }                                                                                                                    \
     template <>                                                                                                          \
     int launch_fused<METHOD>(int src, int mode, const FusedParams& p, int grid, hipStream_t s) {                         \

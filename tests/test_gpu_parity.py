@@ -254,11 +254,15 @@ def test_fused_forward_backward_matches_oracle(dev, case):
     assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "grad G1")
     for nme, a, b in zip(["W1", "b1", "W2", "b2", "W3", "b3"], out.grad_mlp, ref.grad_mlp):
         assert_rel(a, b, 1e-4, nme)
-    # decoder gradients and loss come from a fixed-order reduction: bit-stable run to run
+    # run-to-run: only fp32 summation order may differ (3D: fixed-order reduction -> bit-stable; 2D: the workgroup's waves
+    # add into a shared LDS accumulator in arrival order)
     out2 = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd)
-    assert torch.equal(out.loss, out2.loss)
+    assert_rel(out2.loss, out.loss, 1e-6, "loss run to run")
     for a, b in zip(out.grad_mlp, out2.grad_mlp):
-        assert torch.equal(a, b)
+        if dim == 3:
+            assert torch.equal(a, b)
+        else:
+            assert_rel(a, b, 1e-5, "decoder grads run to run")
 
 
 def test_fused_autograd_function(dev):
@@ -460,8 +464,8 @@ def test_full_size_4k_properties(dev):
     """BASELINE config 2 (3840 x 2160 image, dense G0/G1 pair): too big for the oracle end to end, so
     (a) 64 random 16 x 16 windows are checked against the oracle sample for sample,
     (b) the loss equals an independent reduction of the kernel's own y,
-    (c) tiling invariance: the same pass as 135 crops of 144 x 256 gives the same loss / gradients,
-    (d) decoder gradients are bit-stable run to run."""
+    (c) tiling invariance: the same pass as 225 crops of 144 x 256 gives the same loss / gradients,
+    (d) results are stable run to run up to fp32 summation order."""
     from neural_image_compression_v2_amd import _lib, fused
     H, W = 2160, 3840                                              # first sample axis = image axis 0
     g = torch.Generator().manual_seed(21)
@@ -507,7 +511,9 @@ def test_full_size_4k_properties(dev):
         assert_rel(p_, q_, 1e-4, "tiling: " + nme)
     # (d)
     a2 = fused.fused_forward_backward(geo1, g0d, g1d, [(0, 0)], params, target)
-    assert torch.equal(a.loss, a2.loss) and all(torch.equal(p_, q_) for p_, q_ in zip(a.grad_mlp, a2.grad_mlp))
+    assert_rel(a2.loss, a.loss, 1e-6, "run to run: loss")
+    for p_, q_ in zip(a.grad_mlp, a2.grad_mlp):
+        assert_rel(p_, q_, 1e-5, "run to run: decoder grads")
 
 
 def test_philox_world_size_invariance(dev):
