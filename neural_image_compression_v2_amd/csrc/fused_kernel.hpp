@@ -14,9 +14,14 @@
 //     layer's MFMA wants (k-step = register index): the three forward layers and the two backward
 //     dA products chain through registers with no LDS traffic.  Only the weight-gradient products,
 //     which contract over the sample index, go through a transposed wave-private LDS image.
-//   * the input gradient leaves the last backward product in the registers of the lane that computed
-//     the corresponding grid address in the forward pass; it is scattered with fp32 atomics
-//     (the reference's index_put_(accumulate=True), image_compression.py:265).
+//   * lanes map to grid CELLS, not to consecutive samples: a wave owns a 4 x 8 (2D) / 2 x 4 x 4 (3D) block of G0 cells and
+//     walks the m^D samples inside a cell (m = 1/step_number: 16 rounds at mip 0) one per round.  All samples of a
+//     lane share their G0 corners and their G1 cell, so the input gradient - which leaves the last backward product in
+//     the registers of the lane that knows the slot's grid address - is summed in registers over the rounds and
+//     scattered ONCE per cell with fp32 atomics (the reference's index_put_(accumulate=True),
+//     image_compression.py:265): 16x fewer atomics, no lanes of one instruction on the same address, and no
+//     cross-lane reduction.  (Per-sample atomics ran at the contended memory-side rate; LDS float atomics at about
+//     one lane per clock - both measured and dropped, see DESIGN.md.)
 //   * decoder-gradient accumulators are written once per wave to a workspace and summed in a fixed
 //     order by reduce_partials_kernel (bit-stable decoder gradients and loss).
 #pragma once
@@ -42,8 +47,9 @@ struct FusedParams {
     const float* dy;       // MODE_TRAIN_DY:  [N, 3]
     float* y;              // [N, 3] or null
     float* partials;       // workspace, [n_waves][REC]
-    int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;
+    int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;
+    int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile
     float grad_scale;      // 2 * loss_scale
 };
 
@@ -62,13 +68,7 @@ struct Lds {
     static constexpr int OFF_B2 = OFF_W3 + 4 * LD2;           // W3 rows 0..2 + one zero row (k padding of dA2)
     static constexpr int OFF_B3 = OFF_B2 + kH;
     static constexpr int OFF_SCR = OFF_B3 + 16;
-    // wave-private "node box": the grid nodes one 32-sample tile can touch when step_number <= 1/2, per grid
-    // (2D tile 4 x 8: G0 <= 4 x 6 nodes, G1 <= 3 x 4;  3D tile 2 x 4 x 4: G0 <= 3 x 4 x 4, G1 <= 3 x 3 x 3)
-    static constexpr int BX0 = L::DIM == 2 ? 4 : 3, BY0 = L::DIM == 2 ? 6 : 4, BZ0 = L::DIM == 2 ? 1 : 4;
-    static constexpr int BX1 = 3, BY1 = L::DIM == 2 ? 4 : 3, BZ1 = L::DIM == 2 ? 1 : 3;
-    static constexpr int NB0 = BX0 * BY0 * BZ0, NB1 = BX1 * BY1 * BZ1;
-    static constexpr int BOX = ((NB0 + NB1) * kC + 3) / 4 * 4;
-    static constexpr int SCR_PER_WAVE = 128 * LDT + BOX;      // SA (64 rows) + SB (64 rows) + node boxes
+    static constexpr int SCR_PER_WAVE = 128 * LDT;            // SA (64 rows) + SB (64 rows), wave-private
     static constexpr int TOTAL_INFER = OFF_SCR;
     static constexpr int TOTAL_TRAIN = OFF_SCR + 4 * SCR_PER_WAVE;
     // Decoder-gradient bookkeeping.  The 4 waves of a workgroup split OWNERSHIP of the dW output tiles: each wave
@@ -121,7 +121,6 @@ __host__ __device__ constexpr int ROWC(int r) { return (r & 3) + 8 * (r >> 2); }
 struct EncCtx {
     uint32_t off0, off1;    // element offsets of corner (0,0,0) in G0 / G1 (channel 0); a channel plane is < 2^32 elements
     float kx, ky, kz;       // G1 interpolation fractions
-    int c0[3], c1[3];       // (clamped) cell coordinates of the sample in G0 / G1
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -183,24 +182,35 @@ __device__ __forceinline__ void g0_corner(int e, int h, int& dx, int& dy, int& d
     else { dy = e; dz = h ^ e; }                              // tetra corners 2h + e: dz = dx ^ dy
 }
 
-// Fills the lane's slots (see Layout<> in nic_device.hpp) for sample (ix,iy,iz) of `crop`.
+// element offsets of the (clamped) G0 / G1 cells of absolute sample coordinate q
 template <class L>
-__device__ __forceinline__ void encode_slots(const FusedParams& p, int crop, int ix, int iy, int iz, int h, float (&xs)[L::NSLOT], EncCtx& cx) {
+__device__ __forceinline__ void cell_offsets(const FusedParams& p, const int (&q)[3], uint32_t& off0, uint32_t& off1) {
+    constexpr int D = L::DIM;
+    const int e = p.d.log2_step;
+    const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
+    Axis az;
+    if (D == 3) az = axis_coords(q[2], e);
+    else { az.i0 = az.i1 = 0; az.t1 = az.k1 = 0.f; }
+    off0 = (uint32_t)p.g0.at(clampi(ax.i0, 0, p.g0.nx - 2), clampi(ay.i0, 0, p.g0.ny - 2), D == 3 ? clampi(az.i0, 0, p.g0.nz - 2) : 0);
+    off1 = (uint32_t)p.g1.at(clampi(ax.i1, 0, p.g1.nx - 2), clampi(ay.i1, 0, p.g1.ny - 2), D == 3 ? clampi(az.i1, 0, p.g1.nz - 2) : 0);
+}
+
+// Fills the lane's slots (see Layout<> in nic_device.hpp) for the sample at ABSOLUTE coordinates q = origin + index.
+template <class L>
+__device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q)[3], int h, float (&xs)[L::NSLOT], EncCtx& cx) {
     constexpr int D = L::DIM;
     const nic_path_desc& d = p.d;
     const int e = d.log2_step;
-    Axis ax = axis_coords(p.origins[crop * D + 0] + ix, e);
-    Axis ay = axis_coords(p.origins[crop * D + 1] + iy, e);
+    Axis ax = axis_coords(q[0], e);
+    Axis ay = axis_coords(q[1], e);
     Axis az;
-    if (D == 3) az = axis_coords(p.origins[crop * D + 2] + iz, e);
+    if (D == 3) az = axis_coords(q[2], e);
     else { az.i0 = az.i1 = 0; az.t1 = az.k1 = 0.f; }
     // memory safety: a corner index never leaves the grid, whatever the origins hold
     const int x0 = clampi(ax.i0, 0, p.g0.nx - 2), y0 = clampi(ay.i0, 0, p.g0.ny - 2), z0 = D == 3 ? clampi(az.i0, 0, p.g0.nz - 2) : 0;
     const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2), z1 = D == 3 ? clampi(az.i1, 0, p.g1.nz - 2) : 0;
     cx.off0 = (uint32_t)p.g0.at(x0, y0, z0);
     cx.off1 = (uint32_t)p.g1.at(x1, y1, z1);
-    cx.c0[0] = x0; cx.c0[1] = y0; cx.c0[2] = z0;
-    cx.c1[0] = x1; cx.c1[1] = y1; cx.c1[2] = z1;
     cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = az.k1;
     constexpr int NG0 = L::K0 / 2 * kC;             // G0 slots per half
     // --- G0 raw corners.  Address = (uniform channel-plane base in SGPRs) + (one 32-bit lane offset per corner): the 12
@@ -313,101 +323,68 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
     }
 }
 
-// scatter of the grid-slot gradients (index_put_(accumulate=True) of the gathers' backward), direct form: one global
-// fp32 atomic per lane and slot.  Used when step_number >= 1 (every sample has its own cell: nothing to merge).
-template <class L, int NT>
-__device__ __forceinline__ void scatter_grid_grads(const FusedParams& p, const EncCtx& cx, int h, const f32x16 (&dxacc)[NT]) {
-    constexpr int D = L::DIM;
-    constexpr int NG0 = L::K0 / 2 * kC;
+// Gradients of the lane's grid slots.  Every sample a lane handles inside one macro-tile lies in the same G0 cell (and G1
+// cell), so the slot gradients are summed in registers over the rounds (GridAcc) and scattered once per cell.
+template <class L>
+struct GridAcc {
+    static constexpr int NG0 = L::K0 / 2 * kC;
+    static constexpr int K1 = L::DIM == 2 ? 4 : 8;
+    float g0[NG0];               // [corner e of this half][channel]
+    float g1[K1 * (kC / 2)];     // [corner q][channel of this half]
+    __device__ __forceinline__ void clear() {
 #pragma unroll
-    for (int s = 0; s < NG0; ++s) {
-        int dx, dy, dz;
-        g0_corner<L>(s / kC, h, dx, dy, dz);
-        atomicAdd(p.g0_grad + (int64_t)(s % kC) * p.g0.plane + (cx.off0 + (uint32_t)p.g0.at(dx, dy, dz)), dxacc[s >> 4][s & 15]);
+        for (int i = 0; i < NG0; ++i) g0[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < K1 * (kC / 2); ++i) g1[i] = 0.f;
     }
-    constexpr int K1 = D == 2 ? 4 : 8;
+};
+
+template <class L, int NT>
+__device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, const EncCtx& cx, const f32x16 (&dxacc)[NT], GridAcc<L>& ga) {
+    constexpr int D = L::DIM;
+    constexpr int NG0 = GridAcc<L>::NG0, K1 = GridAcc<L>::K1;
+#pragma unroll
+    for (int s = 0; s < NG0; ++s) ga.g0[s] += dxacc[s >> 4][s & 15];
     const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
-    float w[K1];
 #pragma unroll
-    for (int q = 0; q < K1; ++q) w[q] = g1_corner_factor<D>(gf, q);
+    for (int q = 0; q < K1; ++q) {
+        const float w = g1_corner_factor<D>(gf, q);
 #pragma unroll
-    for (int cc = 0; cc < kC / 2; ++cc) {
-        const int s = NG0 + cc;
-        const float gsum = dxacc[s >> 4][s & 15];
-        float* pc = p.g1_grad + (int64_t)(kC / 2 * h + cc) * p.g1.plane + cx.off1;
-#pragma unroll
-        for (int q = 0; q < K1; ++q) {
-            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
-            atomicAdd(pc + p.g1.at(dx, dy, dz), gsum * w[q]);
+        for (int cc = 0; cc < kC / 2; ++cc) {
+            const int s = NG0 + cc;
+            ga.g1[q * (kC / 2) + cc] = fmaf(dxacc[s >> 4][s & 15], w, ga.g1[q * (kC / 2) + cc]);
         }
     }
 }
 
-// Tile-local form for step_number <= 1/2, where 4^D (G0) / 8^D (G1) samples share a cell at mip 0: every lane adds its
-// slot gradients into a wave-private LDS box of the nodes the tile can touch (ds_add_f32; same-address lanes serialise
-// inside the LDS, ~100x cheaper than at the memory-side atomic units), then the wave flushes each touched node with ONE
-// global atomic.  Per 32-sample tile this replaces 96 wave-atomics whose lanes collide on a handful of addresses by ~8
-// wave-atomics with a distinct address per lane.  (bx, by, bz) = node coordinates of the box origin, wave-uniform.
-template <class L, int NT>
-__device__ __forceinline__ void scatter_grid_grads_box(const FusedParams& p, const EncCtx& cx, int h, int lane, bool valid, lds_f* box,
-                                                       const int (&b0)[3], const int (&b1)[3], const int (&l0)[3], const int (&l1)[3],
-                                                       const f32x16 (&dxacc)[NT]) {
-    using S = Lds<L>;
+// one fp32 atomic per (corner, channel) of the lane's cell; exact zeros (cells outside the crop, zero weights) are skipped
+template <class L>
+__device__ __forceinline__ void flush_grid_grads(const FusedParams& p, uint32_t off0, uint32_t off1, int h, const GridAcc<L>& ga) {
     constexpr int D = L::DIM;
-    constexpr int NG0 = L::K0 / 2 * kC;
-    lds_f* const box0 = box;
-    lds_f* const box1 = box + S::NB0 * kC;
-    if (valid) {
+    constexpr int NG0 = GridAcc<L>::NG0, K1 = GridAcc<L>::K1;
 #pragma unroll
-        for (int s = 0; s < NG0; ++s) {
-            int dx, dy, dz;
-            g0_corner<L>(s / kC, h, dx, dy, dz);
-            const int node = ((l0[2] + dz) * S::BY0 + (l0[1] + dy)) * S::BX0 + l0[0] + dx;
-            lds_add(box0 + (s % kC) * S::NB0 + node, dxacc[s >> 4][s & 15]);
+    for (int e = 0; e < NG0 / kC; ++e) {
+        int dx, dy, dz;
+        g0_corner<L>(e, h, dx, dy, dz);
+        const uint32_t voff = off0 + (uint32_t)p.g0.at(dx, dy, dz);
+#pragma unroll
+        for (int c = 0; c < kC; ++c) {
+            const float v = ga.g0[e * kC + c];
+            float* plane = p.g0_grad + (int64_t)c * p.g0.plane;               // wave-uniform
+            if (v != 0.f) atomicAdd(plane + voff, v);
         }
-        constexpr int K1 = D == 2 ? 4 : 8;
-        const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+    }
+#pragma unroll
+    for (int q = 0; q < K1; ++q) {
+        const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+        const uint32_t voff = off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(kC / 2 * h) * (uint32_t)p.g1.plane;
 #pragma unroll
         for (int cc = 0; cc < kC / 2; ++cc) {
-            const int s = NG0 + cc;
-            const float gsum = dxacc[s >> 4][s & 15];
-#pragma unroll
-            for (int q = 0; q < K1; ++q) {
-                const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
-                const int node = ((l1[2] + dz) * S::BY1 + (l1[1] + dy)) * S::BX1 + l1[0] + dx;
-                lds_add(box1 + (kC / 2 * h + cc) * S::NB1 + node, gsum * g1_corner_factor<D>(gf, q));
-            }
+            const float v = ga.g1[q * (kC / 2) + cc];
+            float* plane = p.g1_grad + (int64_t)cc * p.g1.plane;
+            if (v != 0.f) atomicAdd(plane + voff, v);
         }
     }
-    wave_lds_fence();
-    // flush + re-zero
-#pragma unroll
-    for (int i = 0; i < (S::NB0 * kC + 63) / 64; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < S::NB0 * kC) {
-            const float v = box0[idx];
-            if (v != 0.f) {
-                const int c = idx / S::NB0, node = idx - c * S::NB0;
-                const int x = b0[0] + node % S::BX0, y = b0[1] + (node / S::BX0) % S::BY0, z = b0[2] + node / (S::BX0 * S::BY0);
-                box0[idx] = 0.f;
-                if (x < p.g0.nx && y < p.g0.ny && z < p.g0.nz) atomicAdd(p.g0_grad + (int64_t)c * p.g0.plane + p.g0.at(x, y, z), v);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < (S::NB1 * kC + 63) / 64; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < S::NB1 * kC) {
-            const float v = box1[idx];
-            if (v != 0.f) {
-                const int c = idx / S::NB1, node = idx - c * S::NB1;
-                const int x = b1[0] + node % S::BX1, y = b1[1] + (node / S::BX1) % S::BY1, z = b1[2] + node / (S::BX1 * S::BY1);
-                box1[idx] = 0.f;
-                if (x < p.g1.nx && y < p.g1.ny && z < p.g1.nz) atomicAdd(p.g1_grad + (int64_t)c * p.g1.plane + p.g1.at(x, y, z), v);
-            }
-        }
-    }
-    wave_lds_fence();
 }
 
 // =====================================================================================================
@@ -483,6 +460,38 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // last tile with every lane masked, which contributes exact zeros everywhere
         const bool tile_ok = base + wave < t_end;
         const int64_t tile = tile_ok ? base + wave : t_end - 1;
+        // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
+        int crop = 0;
+        int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
+        if (SRC == SRC_ENCODE) {
+            crop = (int)(tile / p.tiles_per_crop);
+            int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
+            int lc[3], tc[3];
+            if (L::DIM == 2) {
+                lc[0] = pl / L::TY; lc[1] = pl % L::TY; lc[2] = 0;
+                tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y; tc[2] = 0;
+            } else {
+                lc[0] = pl / (L::TY * L::TZ); lc[1] = (pl / L::TZ) % L::TY; lc[2] = pl % L::TZ;
+                tc[2] = tt % p.tiles_z; tt /= p.tiles_z;
+                tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y;
+            }
+            constexpr int T[3] = {L::TX, L::TY, L::TZ};
+#pragma unroll
+            for (int a = 0; a < L::DIM; ++a) {
+                org[a] = p.origins[crop * L::DIM + a];
+                blk[a] = (org[a] >> p.lm) + tc[a] * T[a] + lc[a];
+            }
+        }
+        GridAcc<L> gacc;
+        uint32_t blk_off0 = 0, blk_off1 = 0;
+        if (SRC == SRC_ENCODE && TRAIN) {
+            gacc.clear();
+            const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};
+            cell_offsets<L>(p, qb, blk_off0, blk_off1);
+        }
+
+      for (int it = 0; it < (SRC == SRC_ENCODE ? p.niter : 1); ++it) {          // one sample of the cell block per round
+        // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         lds_cf* const w1_row = opaque(W1s + pl * LD1 + 4 * h);      // A rows of layer 1 (b128 along k)
         lds_cf* const w2_row = opaque(W2s + pl * LD2 + 4 * h);
@@ -499,30 +508,27 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         lds_cf* const sb_lane = opaque(SB + lane * LDT);
         lds_cf* const sa_bc = opaque(SA);                           // broadcast reads of rows 0..2
 
-        // ---------- which sample does this lane own
+        // ---------- which sample does this lane own in this round
         bool valid;
         int64_t n;          // sample index inside this launch
-        int crop = 0, ix = 0, iy = 0, iz = 0;
+        int q[3] = {0, 0, 0};
         if (SRC == SRC_ENCODE) {
-            crop = (int)(tile / p.tiles_per_crop);
-            int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
-            int lx, ly, lz = 0;
-            if (L::DIM == 2) {
-                lx = pl / L::TY; ly = pl % L::TY;
-                const int ty = tt % p.tiles_y, tx = tt / p.tiles_y;
-                ix = tx * L::TX + lx; iy = ty * L::TY + ly;
-            } else {
-                lx = pl / (L::TY * L::TZ); ly = (pl / L::TZ) % L::TY; lz = pl % L::TZ;
-                const int tz = tt % p.tiles_z; tt /= p.tiles_z;
-                const int ty = tt % p.tiles_y, tx = tt / p.tiles_y;
-                ix = tx * L::TX + lx; iy = ty * L::TY + ly; iz = tz * L::TZ + lz;
-            }
+            const int m1 = (1 << p.lm) - 1;
+            int j[3];
+            if (L::DIM == 2) { j[1] = it & m1; j[0] = it >> p.lm; j[2] = 0; }
+            else { j[2] = it & m1; j[1] = (it >> p.lm) & m1; j[0] = it >> (2 * p.lm); }
             const int ez = L::DIM == 3 ? p.d.extent[2] : 1;
-            valid = tile_ok && ix < p.d.extent[0] && iy < p.d.extent[1] && iz < ez;
-            ix = ix < p.d.extent[0] ? ix : p.d.extent[0] - 1;
-            iy = iy < p.d.extent[1] ? iy : p.d.extent[1] - 1;
-            iz = iz < ez ? iz : ez - 1;
-            n = (int64_t)crop * p.n_per_crop + ((int64_t)ix * p.d.extent[1] + iy) * ez + iz;
+            const int ext[3] = {p.d.extent[0], p.d.extent[1], ez};
+            int idx[3] = {0, 0, 0};
+            valid = tile_ok;
+#pragma unroll
+            for (int a = 0; a < L::DIM; ++a) {
+                const int i = (blk[a] << p.lm) + j[a] - org[a];          // index inside the crop
+                valid = valid && i >= 0 && i < ext[a];
+                idx[a] = i < 0 ? 0 : (i >= ext[a] ? ext[a] - 1 : i);     // masked lanes stay inside the crop
+                q[a] = org[a] + idx[a];
+            }
+            n = (int64_t)crop * p.n_per_crop + ((int64_t)idx[0] * ext[1] + idx[1]) * ez + idx[2];
         } else {
             n = tile * 32 + pl;
             valid = tile_ok && n < p.n_total;
@@ -533,7 +539,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         float xs[L::NSLOT];
         EncCtx cx;
         if (SRC == SRC_ENCODE) {
-            encode_slots<L>(p, crop, ix, iy, iz, h, xs, cx);
+            encode_slots<L>(p, q, h, xs, cx);
             add_noise<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, h, xs);
         } else {
             const float* row = p.x + n * L::CIN;
@@ -801,30 +807,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             if (SRC == SRC_ENCODE) {
-                if (p.d.reserved & 1) {
-                    // debug / profiling only: skip the grid-gradient scatter (results are then incomplete)
-                } else if (p.d.log2_step <= -1) {
-                    // box origin = cell of the tile's first sample (wave-uniform); the lane's offset inside the box
-                    int b0[3], b1[3], l0[3], l1[3];
-                    const int tq[3] = {ix - ix % L::TX, iy - iy % L::TY, iz - iz % L::TZ};       // tile origin (clamped lanes included)
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        if (a < L::DIM) {
-                            const Axis t0 = axis_coords(p.origins[crop * L::DIM + a] + tq[a], p.d.log2_step);
-                            const int n0 = a == 0 ? p.g0.nx : (a == 1 ? p.g0.ny : p.g0.nz), n1 = a == 0 ? p.g1.nx : (a == 1 ? p.g1.ny : p.g1.nz);
-                            b0[a] = clampi(t0.i0, 0, n0 - 2);
-                            b1[a] = clampi(t0.i1, 0, n1 - 2);
-                        } else {
-                            b0[a] = b1[a] = 0;
-                        }
-                        constexpr int B0[3] = {S::BX0, S::BY0, S::BZ0}, B1[3] = {S::BX1, S::BY1, S::BZ1};
-                        l0[a] = a < L::DIM ? clampi(cx.c0[a] - b0[a], 0, B0[a] - 2) : 0;
-                        l1[a] = a < L::DIM ? clampi(cx.c1[a] - b1[a], 0, B1[a] - 2) : 0;
-                    }
-                    scatter_grid_grads_box<L, NGT>(p, cx, h, lane, valid, SB + 64 * LDT, b0, b1, l0, l1, dxacc);
-                } else if (valid) {
-                    scatter_grid_grads<L, NGT>(p, cx, h, dxacc);
-                }
+                accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc);        // masked lanes carry exact zeros (dZ3 = 0)
             } else if (valid) {
                 float* row = p.dx + n * L::CIN;
 #pragma unroll
@@ -834,7 +817,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 }
             }
         }
-    }  // tile loop
+      }  // rounds of one macro-tile
+        if (SRC == SRC_ENCODE && TRAIN && !(p.d.reserved & 1)) flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+    }  // macro-tile loop
 
     if (!TRAIN) return;
     // ---------------- flush: ONE record per workgroup; every wave writes the tiles it owns, its partial tiles and its tail

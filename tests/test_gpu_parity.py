@@ -219,15 +219,27 @@ FUSED_CASES = [
     (3, 3, True, 16, (5, 3, 7), [(0, 0, 0), (59, 61, 57)], "philox"),
     (3, 4, False, 16, (8, 8, 8), [(3, 5, 9), (56, 0, 31)], "philox"),
     (3, 4, False, 16, (6, 5, 3), [(1, 2, 3)], "none"),
+    # mip pyramid levels: step 1/2 (2 x 2 samples per cell), 1, 2 (unweighted G1, Q6), 4 - (base, fl, mip) in place of base
+    (2, 1, True, (64, 0, 1), (40, 24), [(3, 5), (50, 30)], "philox"),
+    (2, 1, True, (64, 0, 2), (20, 24), [(3, 5), (20, 7)], "tensor"),
+    (2, 1, False, (64, 0, 3), (10, 9), [(3, 5), (12, 0)], "philox"),
+    (2, 1, True, (64, 1, 4), (7, 5), [(1, 2)], "none"),
+    (2, 1, True, (64, 1, 6), (2, 3), [(0, 1)], "philox"),
+    (3, 3, True, (16, 0, 1), (6, 5, 7), [(1, 2, 3), (20, 9, 0)], "philox"),
+    (3, 4, False, (16, 0, 2), (5, 4, 3), [(1, 2, 3)], "tensor"),
 ]
 
 
-@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: f"d{c[0]}m{c[1]}{'t' if c[2] else 's'}-{'x'.join(map(str, c[4]))}-{c[6]}")
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: f"d{c[0]}m{c[1]}{'t' if c[2] else 's'}-{c[3]}-{'x'.join(map(str, c[4]))}-{c[6]}".replace(" ", ""))
 def test_fused_forward_backward_matches_oracle(dev, case):
     from neural_image_compression_v2_amd import _lib, fused
     dim, method, tri, base, extent, origins, noise_kind = case
-    fp, _ = _pyramid(dim, base, 12, seed=9)
-    g0, g1 = fp
+    fl, mip = 0, 0
+    if isinstance(base, tuple):
+        base, fl, mip = base
+    fp, _ = _pyramid(dim, base, 12, seed=9, no_mip=(mip == 0))
+    g0, g1 = fp[2 * fl], fp[2 * fl + 1]
+    step = O.step_number_of(mip, fl)
     cin = O.decoder_input_channels(12, 6, dim, method)
     g = torch.Generator().manual_seed(77)
     mlp = O.init_mlp(cin, 64, generator=g)
@@ -241,8 +253,8 @@ def test_fused_forward_backward_matches_oracle(dev, case):
     elif noise_kind == "philox":
         noise = O.philox_noise(n, cin, 8, seed=0x1234567890AB, offset=42, sample_base=1000)
         kw = dict(noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=0x1234567890AB, philox_offset=42, sample_base=1000)
-    ref = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, 6, method=method, use_tri_pe=tri)
-    geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), use_tri_pe=tri, **kw)
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, step, mip, target, noise, 6, method=method, use_tri_pe=tri)
+    geo = fused.PathGeometry(dim=dim, method=method, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri, **kw)
     params = [q.to(dev) for q in mlp.tensors()]
     nd = noise.to(dev) if noise_kind == "tensor" else None
     y_inf = fused.fused_forward(geo, g0.to(dev), g1.to(dev), origins, params, nd)
