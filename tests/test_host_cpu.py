@@ -1,0 +1,211 @@
+"""CPU-only tests (run with -m "not gpu"): the C-ABI library loads and exports every symbol the header declares, the
+ctypes mirror of nic_path_desc matches the C layout (checked against gcc), host logic (settings, level maps, geometry
+validation, gradient bucket layout), no product path runs without a HIP device, and the data-parallel sharding /
+bucket all-reduce logic over gloo with the CPU oracle injected as the step function."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nicv2_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from neural_image_compression_v2_amd import _build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nic_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from neural_image_compression_v2_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nicv2_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
+    assert lib.nic_abi_version() == 1
+    assert lib.nic_error_string(-2).decode().startswith("unsupported")
+    assert lib.nic_decoder_input_channels(2, 1, 12, 6) == 73          # var2.py:114-118
+    assert lib.nic_decoder_input_channels(3, 3, 12, 6) == 127
+    assert lib.nic_decoder_input_channels(3, 4, 12, 6) == 79
+    assert lib.nic_workspace_bytes(None) > 0                           # no GPU call involved
+
+
+def test_path_desc_layout_matches_the_c_header():
+    from neural_image_compression_v2_amd._lib import NicMlp, NicPathDesc
+    fields = [f[0] for f in NicPathDesc._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(){",
+            'printf("%zu\\n", sizeof(nic_path_desc));']
+    prog += [f'printf("%zu\\n", offsetof(nic_path_desc, {f}));' for f in fields]
+    prog += ['printf("%zu\\n", sizeof(nic_mlp));', "return 0;}"]
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(prog))
+        subprocess.run(["gcc", "-std=c11", src, "-o", exe], check=True)
+        vals = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(NicPathDesc)
+    for f, off in zip(fields, vals[1:-1]):
+        assert getattr(NicPathDesc, f).offset == off, f
+    assert vals[-1] == ctypes.sizeof(NicMlp)
+
+
+def test_no_cpu_path():
+    """every product entry point refuses CPU tensors instead of computing something else"""
+    from neural_image_compression_v2_amd import fp_def, fused, models, utils
+    from neural_image_compression_v2_amd.image_compression import ColorDecoder, ImageCompression
+    x = torch.zeros(4, 73)
+    for fn in (lambda: models.quantize4fp(x, 8), lambda: models.save4fp(x, 8), lambda: models.quantize_to_bit(x),
+               lambda: utils.triangular_positional_encoding(torch.zeros(2, 5), 6), lambda: utils.calculate_psnr(x, x),
+               lambda: ColorDecoder()(x), lambda: fp_def.fp_quantize_clamp([x, x], 0, 8)):
+        with pytest.raises(RuntimeError):
+            fn()
+    geo = fused.PathGeometry(2, 1, 0.25, 0, (8, 8), 1)
+    with pytest.raises(RuntimeError):
+        fused.encode(geo, torch.zeros(12, 17, 17), torch.zeros(12, 9, 9), [(0, 0)])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ImageCompression()
+
+
+def test_oracle_is_not_imported_by_the_product():
+    pkg = os.path.join(ROOT, "neural_image_compression_v2_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.+oracle\b)|nic_oracle\s*(as|\.|import)", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} imports the oracle"
+
+
+def test_settings_and_level_maps():
+    from neural_image_compression_v2_amd import fp_def
+    from neural_image_compression_v2_amd.var2 import Settings
+    s = Settings.from_argv(["IMAGE_PATH=data/x.npy", "FP_BITS=4", "NUM_EPOCHS=320000", "COMPRESSION_METHOD=4", "IMAGE_DIMENSION=3",
+                            "IMAGE_SIZE=64", "CROP_MIP_LEVEL=5", "TF_USE_TRI_PE=False", "UNIFORM_DISTRIBUTION_RATE=0.1"])   # the .bat sweeps
+    assert (s.FP_BITS, s.NUM_EPOCHS, s.COMPRESSION_METHOD, s.IMAGE_SIZE, s.CROP_MIP_LEVEL) == (4, 320000, 4, 64, 5)
+    assert s.TF_USE_TRI_PE is False and s.UNIFORM_DISTRIBUTION_RATE == 0.1 and s.IMAGE_PATH == "data/x.npy"
+    assert s.DECODER_INPUT_CHANNELS == 79 and s.FEATURE_PYRAMID_SIZE == 16 and s.CROP_SIZE == 32 and s.MAX_MIP_LEVEL == 0
+    assert Settings().DECODER_INPUT_CHANNELS == 73 and Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3).DECODER_INPUT_CHANNELS == 127
+    assert Settings(TF_NO_MIP=False).MAX_MIP_LEVEL == 9
+    with pytest.raises(ValueError):
+        Settings.from_argv(["TF_NO_MIP=maybe"])
+    assert dict(fp_def.create_pyramid_mip_levels(512, 128)) == {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 2, 7: 2, 8: 3, 9: 3}
+    assert fp_def.return_pyramid_levels(128) == 4 and fp_def.return_2_power(1024) == 10          # test03.py prints
+
+
+def test_geometry_and_validation():
+    from neural_image_compression_v2_amd import _lib, fused
+    g0, g1 = torch.zeros(12, 961, 541), torch.zeros(12, 481, 271)                               # SURVEY 8d config 2 grids
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(2160, 3840), num_crops=1)
+    d = geo.to_desc(g0, g1)
+    assert (d.g0_nodes[0], d.g0_nodes[1], d.g1_nodes[0], d.g1_nodes[1]) == (541, 961, 271, 481)
+    assert d.log2_step == -2 and d.g1_weight_mode == _lib.NIC_G1_REFERENCE and abs(d.loss_scale - 1 / (3 * 2160 * 3840)) < 1e-15
+    assert geo.cin == 73 and geo.n_samples == 2160 * 3840
+    fused.check_origins(geo, torch.tensor([[0, 0]]), g0, g1)
+    with pytest.raises(IndexError):
+        fused.check_origins(geo, torch.tensor([[1, 0]]), g0, g1)                                # one sample past the grid
+    with pytest.raises(IndexError):
+        fused.check_origins(geo, torch.tensor([[-1, 0]]), g0, g1)
+    # Q6: only step_number == 2 switches the G1 weights off
+    for e in range(-3, 4):
+        geo2 = fused.PathGeometry(2, 1, pow(2, e), 0, (4, 4), 1)
+        assert (geo2.g1_mode() == _lib.NIC_G1_UNWEIGHTED) == (e == 1)
+    with pytest.raises(ValueError):
+        fused.log2_step_of(3)
+    # method fixes the PE family in 3D (fp_def.py:169, 208)
+    assert fused.PathGeometry(3, 3, 0.25, 0, (4, 4, 4), 1, use_tri_pe=False).use_tri_pe is True
+    assert fused.PathGeometry(3, 4, 0.25, 0, (4, 4, 4), 1, use_tri_pe=True).use_tri_pe is False
+    # the sinusoidal divisors are torch's own fp32 values (utils.py:202)
+    import math
+    ref = torch.exp(torch.arange(0, 6, 2, dtype=torch.float32) * -(math.log(10000.0) / 6))
+    assert fused.sinusoidal_div_term(6) == [float(v) for v in ref]
+    offs, sizes, total = fused.grad_bucket_layout(geo, g0, g1)
+    assert sizes[1:7] == [64 * 73, 64, 64 * 64, 64, 192, 3] and sizes[7] == g0.numel() and all(o % 4 == 0 for o in offs)
+    assert total >= sum(sizes)
+
+
+def test_shard_range_covers_everything():
+    from neural_image_compression_v2_amd.distributed import plan_shard, shard_range
+    for n in (1, 7, 8, 9, 135):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for s, c in spans:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    p = plan_shard(8, 65536, rank=3, world=8)
+    assert (p.crop_start, p.crop_count, p.sample_base, p.n_global) == (3, 1, 3 * 65536, 8 * 65536)
+
+
+# ------------------------------------------------------------------------------------------------ world_size 2 over gloo
+def _oracle_step(geo, g0, g1, org, params, target, **kw):
+    """CPU oracle with the product's step signature (test-only backend for distributed.data_parallel_step)"""
+    from neural_image_compression_v2_amd import fused
+    from oracle import nic_oracle as O
+    mlp = O.MLPParams([params[0], params[2], params[4]], [params[1], params[3], params[5]])
+    noise = O.philox_noise(geo.n_samples, geo.cin, geo.num_bits, geo.philox_seed, geo.philox_offset, geo.sample_base)
+    r = O.forward_backward(g0, g1, mlp, [tuple(int(v) for v in o) for o in org], geo.extent, geo.step_number, geo.mip_level, target, noise,
+                           geo.pe_channels, method=geo.method, use_tri_pe=geo.use_tri_pe, mean_over=int(round(1 / (3 * geo.loss_scale))))
+    offs, sizes, total = fused.grad_bucket_layout(geo, g0, g1)
+    flat = torch.zeros(total)
+    parts = [r.loss.reshape(1)] + [g.reshape(-1) for g in r.grad_mlp] + [r.grad_g0.reshape(-1), r.grad_g1.reshape(-1)]
+    for o, part in zip(offs, parts):
+        flat[o:o + part.numel()] = part
+    return fused.StepOutput(flat[0], None, flat[offs[7]:offs[7] + sizes[7]].view(g0.shape), flat[offs[8]:offs[8] + sizes[8]].view(g1.shape),
+                            [flat[offs[1 + i]:offs[1 + i] + sizes[1 + i]] for i in range(6)], flat)
+
+
+def _dp_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from neural_image_compression_v2_amd import _lib, fused
+        from neural_image_compression_v2_amd.distributed import data_parallel_step
+        from oracle import nic_oracle as O
+        torch.set_num_threads(2)
+        g = torch.Generator().manual_seed(1)
+        fp, _ = O.create_pyramid(16, 12, 8, no_mip=True, generator=g)
+        mlp = O.init_mlp(73, 64, generator=g)
+        origins = torch.tensor([[0, 0], [10, 20], [33, 7], [40, 40], [5, 48]])            # 5 crops over 2 ranks: 3 + 2
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(16, 16), num_crops=5,
+                                 noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=5, philox_offset=9)
+        target = torch.rand(geo.n_samples, 3, generator=g)
+        out = data_parallel_step(_oracle_step, geo, fp[0].detach(), fp[1].detach(), origins, mlp.tensors(), target)
+        if rank == 0:
+            single = _oracle_step(geo, fp[0].detach(), fp[1].detach(), origins, mlp.tensors(), target)
+            torch.save({"dp": out.flat, "single": single.flat}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_matches_single_process_gloo():
+    """2 ranks, 5 crops: per-rank oracle steps with the global loss scale and global sample ids, ONE all-reduce of the flat
+    bucket == the single-process step on all crops (loss, decoder grads, grid grads)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.pt")
+        mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+        r = torch.load(out)
+    err = float((r["dp"] - r["single"]).abs().max() / r["single"].abs().max())
+    assert err < 1e-6, err
