@@ -164,7 +164,7 @@ def _oracle_step(geo, g0, g1, org, params, target, **kw):
     mlp = O.MLPParams([params[0], params[2], params[4]], [params[1], params[3], params[5]])
     noise = O.philox_noise(geo.n_samples, geo.cin, geo.num_bits, geo.philox_seed, geo.philox_offset, geo.sample_base)
     r = O.forward_backward(g0, g1, mlp, [tuple(int(v) for v in o) for o in org], geo.extent, geo.step_number, geo.mip_level, target, noise,
-                           geo.pe_channels, method=geo.method, use_tri_pe=geo.use_tri_pe, mean_over=int(round(1 / (3 * geo.loss_scale))))
+                           geo.pe_channels, method=geo.method, use_tri_pe=geo.use_tri_pe, mean_over=(geo.n_samples if geo.loss_scale is None else int(round(1 / (3 * geo.loss_scale)))))
     offs, sizes, total = fused.grad_bucket_layout(geo, g0, g1)
     flat = torch.zeros(total)
     parts = [r.loss.reshape(1)] + [g.reshape(-1) for g in r.grad_mlp] + [r.grad_g0.reshape(-1), r.grad_g1.reshape(-1)]
