@@ -13,7 +13,7 @@ from typing import Optional
 import torch  # imported before the library so libamdhip64.so.7 resolves to the runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnicv2_hip.so")
+LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
 NIC_ABI_VERSION = 1
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1

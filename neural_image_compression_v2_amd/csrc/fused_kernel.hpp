@@ -70,7 +70,12 @@ struct Lds {
     static constexpr int OFF_SCR = OFF_B3 + 16;
     static constexpr int SCR_PER_WAVE = 128 * LDT;            // SA (64 rows) + SB (64 rows), wave-private
     static constexpr int TOTAL_INFER = OFF_SCR;
-    static constexpr int TOTAL_TRAIN = OFF_SCR + 4 * SCR_PER_WAVE;
+    // Where the 160 KiB allow it (2D layouts), every wave also keeps a permanent transposed image of its input X
+    // ([KPAD rows][32 samples]): the input registers die right after layer 1 and dW1 needs no re-staging of X.
+    static constexpr int XIMG_PER_WAVE = KPAD * LDT;           // rows beyond KPAD of the last 32-row tile do not exist
+    static constexpr bool XIMG = (OFF_SCR + 4 * (SCR_PER_WAVE + XIMG_PER_WAVE)) * 4 <= 163840;
+    static constexpr int OFF_XIMG = OFF_SCR + 4 * SCR_PER_WAVE;
+    static constexpr int TOTAL_TRAIN = OFF_XIMG + (XIMG ? 4 * XIMG_PER_WAVE : 0);
     // Decoder-gradient bookkeeping.  The 4 waves of a workgroup split OWNERSHIP of the dW output tiles: each wave
     // contracts its tiles over the transposed operands of all 4 waves (K = 128 samples per round), so a wave carries
     // 3-4 accumulator tiles (48-64 registers) through the launch instead of all NACC (160-192).  The odd col-tile of dW1
@@ -550,6 +555,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             }
         }
 
+        if (TRAIN && S::XIMG) {
+            // permanent transposed image of X for dW1 (read by all four waves after the round's barriers)
+            lds_f* const xi_st = opaque(sm + S::OFF_XIMG + wave * S::XIMG_PER_WAVE + 4 * h * LDT + pl);
+#pragma unroll
+            for (int s = 0; s < L::NSLOT; ++s) xi_st[(32 * (s >> 4) + ROWC(s & 15)) * LDT] = xs[s];
+        }
         // ---------- layer 1: Z1[o][s] = sum_rho W1p[o][rho] X[rho][s]   (bias rides on the constant-one slot)
         f32x16 a1[2], d1[2];
         {
@@ -747,7 +758,50 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             dz1[1] = acc[1] * d1[1];
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---------- dW1[o][rho] += sum_s dZ1[o][s] X[rho][s]   (X staged two 32-row tiles at a time)
+        // ---------- dW1[o][rho] += sum_s dZ1[o][s] X[rho][s]
+        if (S::XIMG) {
+            // X^T of every wave is already in LDS: publish dZ1^T, then each wave contracts the tiles it owns
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sa_st[(32 * t + ROWC(r)) * LDT] = dz1[t][r];
+            wg_lds_barrier();
+            lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to1 * LDT);
+            lds_cf* const xi_o = opaque(sm + S::OFF_XIMG + pl * LDT + 16 * h + 32 * tk1 * LDT);
+#pragma unroll
+            for (int c2 = 0; c2 < NCH; ++c2) {
+#pragma unroll
+                for (int src = 0; src < 4; ++src) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a = ld4(&sa_o[src * S::SCR_PER_WAVE + 4 * g]);
+                        const f32x4 b = ld4(&xi_o[src * S::XIMG_PER_WAVE + 64 * c2 * LDT + 4 * g]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accW1o[c2] = mfma32(a[j], b[j], accW1o[c2]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (S::PART) {
+                // odd last col tile: both row tiles over this wave's own samples
+                constexpr int ROWS_LAST = S::KPAD - 32 * (KT - 1);         // lanes past the image re-read a valid row: their columns
+                const int prow = pl < ROWS_LAST ? pl : pl - ROWS_LAST;     // (rho >= KPAD) are discarded by the reduction
+                lds_cf* const xi_w = opaque(sm + S::OFF_XIMG + wave * S::XIMG_PER_WAVE + prow * LDT + 16 * h + 32 * (KT - 1) * LDT);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = ld4(&xi_w[4 * g]);
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        const f32x4 a = ld4(&sa_rd[32 * to * LDT + 4 * g]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accW1p[to] = mfma32(a[j], b[j], accW1p[to]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wg_lds_barrier();                  // all reads of dZ1^T / X^T done before the next round overwrites them
+        } else {
+        // (X staged two 32-row tiles at a time through SB)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -789,6 +843,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 }
                 wave_lds_fence();
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---------- dX = W1p^T dZ1 for the slots that need it
