@@ -98,6 +98,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Phase timing for a DIAGNOSTIC build (-DNIC_STAMPS, see ab/stamps.py): s_memtime at phase boundaries, per-phase sums kept in
+// scalars and dumped by lane 0 of every wave to the unused tail of the workspace.  The shipped library is built without it.
+#ifdef NIC_STAMPS
+#define NIC_NPH 14
+#define STAMP(ph)                                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        stamp_sum[ph] += t_ - stamp_last;                                                           \
+        stamp_last = t_;                                                                            \
+    } while (0)
+#else
+#define STAMP(ph) do { } while (0)
+#endif
+
 // Workgroup barrier for LDS hand-offs.  NOT __syncthreads(): that also drains vmcnt, i.e. waits for the previous tile's
 // fire-and-forget gradient atomics (thousands of cycles); only this wave's LDS traffic has to be complete here.
 __device__ __forceinline__ void wg_lds_barrier() {
@@ -460,6 +477,13 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     const int64_t t_end = t_begin + chunk < p.n_tiles ? t_begin + chunk : p.n_tiles;
     const int lstride = nb8 * 4;
 
+#ifdef NIC_STAMPS
+    unsigned long long stamp_sum[NIC_NPH];
+#pragma unroll
+    for (int i = 0; i < NIC_NPH; ++i) stamp_sum[i] = 0;
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (int64_t base = t_begin + (int64_t)(blockIdx.x >> 3) * 4; base < t_end; base += lstride) {
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
         // last tile with every lane masked, which contributes exact zeros everywhere
@@ -495,6 +519,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             cell_offsets<L>(p, qb, blk_off0, blk_off1);
         }
 
+        STAMP(12);   // macro-tile setup
       for (int it = 0; it < (SRC == SRC_ENCODE ? p.niter : 1); ++it) {          // one sample of the cell block per round
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
@@ -555,6 +580,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             }
         }
 
+        STAMP(0);    // coordinates, gathers, blend, PE, noise
         if (TRAIN && S::XIMG) {
             // permanent transposed image of X for dW1 (read by all four waves after the round's barriers)
             lds_f* const xi_st = opaque(sm + S::OFF_XIMG + wave * S::XIMG_PER_WAVE + 4 * h * LDT + pl);
@@ -626,6 +652,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);    // X^T store, layers 1 + 2 (MFMA) and their GELUs
         // ---------- layer 3: only 3 outputs - a 32-row MFMA tile would be 90 % padding, so each lane dots its
         // 32 hidden values with the matching W3 columns (broadcast LDS reads) and the two halves are added
         float yv[3];
@@ -707,6 +734,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);    // layer 3, y store, dZ3, dW3 row pass, dA2
         // ---------- dW2[o][k] += sum_s dZ2[o][s] A1[k][s]: every wave publishes its transposed operands, then contracts the
         // ONE tile it owns over the samples of all four waves
         wave_lds_fence();
@@ -723,7 +751,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             const f32x4 zv = ld4(&sa_lane[4 * g]);
             accB2 += (zv[0] + zv[1]) + (zv[2] + zv[3]);
         }
+        STAMP(3);    // dZ2^T / A1^T stores, db2 row pass
         wg_lds_barrier();
+        STAMP(4);    // wait at barrier 1
         {
             lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to2 * LDT);
             lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk2 * LDT);
@@ -739,7 +769,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(5);    // dW2 MFMAs (owned tile, 4 sources)
         wg_lds_barrier();                                              // everyone is done reading before the operands are replaced
+        STAMP(6);    // wait at barrier 2
         __builtin_amdgcn_sched_barrier(0);
         // ---------- dA1 = W2^T dZ2, dZ1 = dA1 * gelu'(Z1)
         f32x16 dz1[2];
@@ -765,7 +797,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sa_st[(32 * t + ROWC(r)) * LDT] = dz1[t][r];
+            STAMP(7);    // dA1 MFMAs, dZ1, dZ1^T store
             wg_lds_barrier();
+            STAMP(8);    // wait at barrier 3
             lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to1 * LDT);
             lds_cf* const xi_o = opaque(sm + S::OFF_XIMG + pl * LDT + 16 * h + 32 * tk1 * LDT);
 #pragma unroll
@@ -799,7 +833,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            STAMP(9);    // dW1 MFMAs (owned + partial tiles)
             wg_lds_barrier();                  // all reads of dZ1^T / X^T done before the next round overwrites them
+            STAMP(10);   // wait at barrier 4
         } else {
         // (X staged two 32-row tiles at a time through SB)
 #pragma unroll
@@ -872,9 +908,18 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 }
             }
         }
+        STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
         if (SRC == SRC_ENCODE && TRAIN && !(p.d.reserved & 1)) flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+        STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
+#ifdef NIC_STAMPS
+    if (lane == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (8u << 20)) + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+        for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
 
     if (!TRAIN) return;
     // ---------------- flush: ONE record per workgroup; every wave writes the tiles it owns, its partial tiles and its tail
