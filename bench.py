@@ -112,7 +112,7 @@ def main():
 
     def step(i, events=None):
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
-                                 noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=7, philox_offset=i,
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
                                  sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global))
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
         all_reduce_flat(out.flat)                                     # RCCL sum of [loss | decoder grads | grid grads]

@@ -54,7 +54,7 @@ enum {
 enum {
     NIC_NOISE_NONE = 0,
     NIC_NOISE_TENSOR = 1,  /* caller supplies the [N, Cin] noise (parity with torch.rand_like, image_compression.py:250) */
-    NIC_NOISE_PHILOX = 2   /* generated in-kernel, Philox-4x32-10 keyed by (seed, offset, global sample id, channel) */
+    NIC_NOISE_KERNEL = 2   /* generated in-kernel: Threefry-4x32-12 keyed by (seed, offset, global sample id, channel block) */
 };
 
 /* Geometry of one launch: which grid pair, which samples.  Mirrors the arguments of
@@ -77,8 +77,8 @@ typedef struct nic_path_desc {
     float pe_div[8];         /* sinusoidal div_term, fp32, pe_channels/2 entries (utils.py:202) */
     int32_t noise_mode;      /* NIC_NOISE_* */
     int32_t num_bits;        /* FP_BITS: noise amplitude 2^-num_bits (image_compression.py:250) */
-    uint64_t philox_seed;
-    uint64_t philox_offset;  /* e.g. the training step */
+    uint64_t noise_seed;
+    uint64_t noise_offset;  /* e.g. the training step */
     int64_t sample_base;     /* global id of this launch's sample 0 (data-parallel shards: keeps the noise world-size invariant) */
     float loss_scale;        /* 1 / (3 * N_global): the MSELoss mean (image_compression.py:259) */
     int32_t reserved;

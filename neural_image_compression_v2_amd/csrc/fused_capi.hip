@@ -99,8 +99,8 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.n_tiles = p.tiles_per_crop * d->num_crops;
     p.noise.mode = d->noise_mode;
     p.noise.tensor = noise;
-    p.noise.k0 = (uint32_t)d->philox_seed; p.noise.k1 = (uint32_t)(d->philox_seed >> 32);
-    p.noise.off_lo = (uint32_t)d->philox_offset; p.noise.off_hi = (uint32_t)(d->philox_offset >> 32);
+    p.noise.k0 = (uint32_t)d->noise_seed; p.noise.k1 = (uint32_t)(d->noise_seed >> 32);
+    p.noise.off_lo = (uint32_t)d->noise_offset; p.noise.off_hi = (uint32_t)(d->noise_offset >> 32);
     p.noise.scale = ldexpf(1.0f, -d->num_bits);
     p.grad_scale = 2.0f * d->loss_scale;
 }

@@ -128,21 +128,31 @@ __device__ __forceinline__ float gelu_only(float z) {
 __device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }   // v_rcp_f32: 1 ulp
 
 // ---------------------------------------------------------------------------------------------------
-// Philox-4x32-10; noise definition restated in oracle/nic_oracle.py::philox_noise
+// In-kernel noise: Threefry-4x32-12 (add / rotate / xor only: full-rate VALU; Philox's 32-bit multiplies are quarter-rate on
+// CDNA and cost ~4.7K of a 58K-cycle round).  Definition restated in oracle/nic_oracle.py::kernel_noise.
 // ---------------------------------------------------------------------------------------------------
 struct U4 {
     uint32_t x, y, z, w;
 };
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ U4 threefry4x32_12(U4 c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    const uint32_t ks[5] = {k0, k1, k2, k3, 0x1BD11BDAu ^ k0 ^ k1 ^ k2 ^ k3};
+    uint32_t x0 = c.x + ks[0], x1 = c.y + ks[1], x2 = c.z + ks[2], x3 = c.w + ks[3];
+    constexpr int R[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+    for (int r = 0; r < 12; ++r) {
+        if ((r & 1) == 0) {
+            x0 += x1; x1 = __builtin_rotateleft32(x1, R[r & 7][0]) ^ x0;
+            x2 += x3; x3 = __builtin_rotateleft32(x3, R[r & 7][1]) ^ x2;
+        } else {
+            x0 += x3; x3 = __builtin_rotateleft32(x3, R[r & 7][0]) ^ x0;
+            x2 += x1; x1 = __builtin_rotateleft32(x1, R[r & 7][1]) ^ x2;
+        }
+        if (((r + 1) & 3) == 0) {
+            const int q = (r + 1) >> 2;
+            x0 += ks[q % 5]; x1 += ks[(q + 1) % 5]; x2 += ks[(q + 2) % 5]; x3 += ks[(q + 3) % 5] + (uint32_t)q;
+        }
     }
-    return c;
+    return U4{x0, x1, x2, x3};
 }
 
 struct NoiseSrc {
@@ -152,10 +162,10 @@ struct NoiseSrc {
     float scale;            // 2^-num_bits
 };
 
-// one Philox block = 8 channels (4 words x 2 halves) of one sample
+// one generator block = 8 channels (4 words x 2 halves) of one sample
 __device__ __forceinline__ U4 noise_block(const NoiseSrc& ns, uint64_t sample, int blk) {
     U4 c{(uint32_t)sample, (uint32_t)blk + ((uint32_t)(sample >> 32) << 8), ns.off_lo, ns.off_hi};
-    return philox4x32_10(c, ns.k0, ns.k1);
+    return threefry4x32_12(c, ns.k0, ns.k1, 0x4E494332u /* "NIC2" */, 0u);
 }
 __device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& b, int ch) {
     const int w = (ch >> 1) & 3;

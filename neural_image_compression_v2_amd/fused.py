@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple, Union
 import torch
 
 from . import _lib
-from ._lib import (NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED, NIC_NOISE_NONE, NIC_NOISE_PHILOX,
+from ._lib import (NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED, NIC_NOISE_NONE, NIC_NOISE_KERNEL,
                    NIC_NOISE_TENSOR, NIC_PE_SINUSOIDAL, NIC_PE_TRIANGULAR)
 
 
@@ -59,8 +59,8 @@ class PathGeometry:
     textbook_weights: bool = False
     noise_mode: int = NIC_NOISE_NONE
     num_bits: int = 8
-    philox_seed: int = 0
-    philox_offset: int = 0
+    noise_seed: int = 0
+    noise_offset: int = 0
     sample_base: int = 0
     loss_scale: Optional[float] = None   # default 1 / (3 N)
 
@@ -111,8 +111,8 @@ class PathGeometry:
             d.pe_div[i] = div[i] if i < len(div) else 0.0
         d.noise_mode = int(self.noise_mode)
         d.num_bits = int(self.num_bits)
-        d.philox_seed = int(self.philox_seed) & 0xFFFFFFFFFFFFFFFF
-        d.philox_offset = int(self.philox_offset) & 0xFFFFFFFFFFFFFFFF
+        d.noise_seed = int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF
+        d.noise_offset = int(self.noise_offset) & 0xFFFFFFFFFFFFFFFF
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.reserved = int(os.environ.get("NIC_DEBUG_FLAGS", "0"))     # profiling experiments only (bit 0: skip the grid-gradient scatter)

@@ -149,8 +149,8 @@ class ImageCompression:
         target = inputs.reshape(-1, 3)
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
-                                 noise_mode=_lib.NIC_NOISE_PHILOX if noisy else _lib.NIC_NOISE_NONE,
-                                 philox_seed=noise_seed, philox_offset=epoch)
+                                 noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
+                                 noise_seed=noise_seed, noise_offset=epoch)
             out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target)
             self.optimizer.zero_grad(set_to_none=True)
             fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1

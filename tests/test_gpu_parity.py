@@ -212,20 +212,20 @@ def test_decoder_matches_reference_golden(dev, golden):
 FUSED_CASES = [
     # dim, method, tri, base, extent, origins, noise
     (2, 1, True, 64, (64, 64), [(17, 101), (0, 0), (192, 192)], "tensor"),
-    (2, 1, True, 64, (37, 21), [(3, 5), (200, 100)], "philox"),
+    (2, 1, True, 64, (37, 21), [(3, 5), (200, 100)], "kernel"),
     (2, 1, False, 64, (40, 24), [(3, 5), (20, 0)], "none"),
-    (2, 1, True, 64, (256, 256), [(0, 0), (0, 0)], "philox"),          # the reference's default crop shape
+    (2, 1, True, 64, (256, 256), [(0, 0), (0, 0)], "kernel"),          # the reference's default crop shape
     (3, 3, True, 16, (8, 8, 8), [(3, 5, 9), (56, 0, 31)], "tensor"),
-    (3, 3, True, 16, (5, 3, 7), [(0, 0, 0), (59, 61, 57)], "philox"),
-    (3, 4, False, 16, (8, 8, 8), [(3, 5, 9), (56, 0, 31)], "philox"),
+    (3, 3, True, 16, (5, 3, 7), [(0, 0, 0), (59, 61, 57)], "kernel"),
+    (3, 4, False, 16, (8, 8, 8), [(3, 5, 9), (56, 0, 31)], "kernel"),
     (3, 4, False, 16, (6, 5, 3), [(1, 2, 3)], "none"),
     # mip pyramid levels: step 1/2 (2 x 2 samples per cell), 1, 2 (unweighted G1, Q6), 4 - (base, fl, mip) in place of base
-    (2, 1, True, (64, 0, 1), (40, 24), [(3, 5), (50, 30)], "philox"),
+    (2, 1, True, (64, 0, 1), (40, 24), [(3, 5), (50, 30)], "kernel"),
     (2, 1, True, (64, 0, 2), (20, 24), [(3, 5), (20, 7)], "tensor"),
-    (2, 1, False, (64, 0, 3), (10, 9), [(3, 5), (12, 0)], "philox"),
+    (2, 1, False, (64, 0, 3), (10, 9), [(3, 5), (12, 0)], "kernel"),
     (2, 1, True, (64, 1, 4), (7, 5), [(1, 2)], "none"),
-    (2, 1, True, (64, 1, 6), (2, 3), [(0, 1)], "philox"),
-    (3, 3, True, (16, 0, 1), (6, 5, 7), [(1, 2, 3), (20, 9, 0)], "philox"),
+    (2, 1, True, (64, 1, 6), (2, 3), [(0, 1)], "kernel"),
+    (3, 3, True, (16, 0, 1), (6, 5, 7), [(1, 2, 3), (20, 9, 0)], "kernel"),
     (3, 4, False, (16, 0, 2), (5, 4, 3), [(1, 2, 3)], "tensor"),
 ]
 
@@ -250,9 +250,9 @@ def test_fused_forward_backward_matches_oracle(dev, case):
     if noise_kind == "tensor":
         noise = (torch.rand(n, cin, generator=g) - 0.5) / 256
         kw = dict(noise_mode=_lib.NIC_NOISE_TENSOR)
-    elif noise_kind == "philox":
-        noise = O.philox_noise(n, cin, 8, seed=0x1234567890AB, offset=42, sample_base=1000)
-        kw = dict(noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=0x1234567890AB, philox_offset=42, sample_base=1000)
+    elif noise_kind == "kernel":
+        noise = O.kernel_noise(n, cin, 8, seed=0x1234567890AB, offset=42, sample_base=1000)
+        kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=0x1234567890AB, noise_offset=42, sample_base=1000)
     ref = O.forward_backward(g0, g1, mlp, origins, extent, step, mip, target, noise, 6, method=method, use_tri_pe=tri)
     geo = fused.PathGeometry(dim=dim, method=method, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri, **kw)
     params = [q.to(dev) for q in mlp.tensors()]
@@ -489,7 +489,7 @@ def test_full_size_4k_properties(dev):
     g0d, g1d = g0.to(dev), g1.to(dev)
     N = H * W
     target = torch.rand(N, 3, generator=g).to(dev)
-    kw = dict(noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=7, philox_offset=3)
+    kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=3)
     geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, **kw)
     out = fused.fused_forward_backward(geo, g0d, g1d, [(0, 0)], params, target, want_y=True)
     # (a)
@@ -499,7 +499,7 @@ def test_full_size_4k_properties(dev):
         ix = torch.arange(ox, ox + 16).repeat_interleave(16)
         iy = torch.arange(oy, oy + 16).repeat(16)
         rows = ix * W + iy
-        noise = torch.stack([O.philox_noise(1, 73, 8, seed=7, offset=3, sample_base=int(r))[0] for r in rows[::37]])
+        noise = torch.stack([O.kernel_noise(1, 73, 8, seed=7, offset=3, sample_base=int(r))[0] for r in rows[::37]])
         x = O.create_decoder_input(g0, g1, [(ox, oy)], (16, 16), 0.25, 0, 6)[::37]
         yr = O.mlp_forward(x + noise, mlp)
         assert_rel(out.y[rows[::37].to(dev)], yr, 5e-6, "window rows")
@@ -528,7 +528,7 @@ def test_full_size_4k_properties(dev):
         assert_rel(p_, q_, 1e-5, "run to run: decoder grads")
 
 
-def test_philox_world_size_invariance(dev):
+def test_kernel_noise_world_size_invariance(dev):
     """a launch over samples [s0, s1) with sample_base = s0 sees the same noise as the matching rows of one big launch"""
     from neural_image_compression_v2_amd import _lib, fused
     fp, _ = _pyramid(2, 64, 12, seed=3)
@@ -536,7 +536,7 @@ def test_philox_world_size_invariance(dev):
     mlp = O.init_mlp(73, 64, generator=g)
     params = [q.to(dev) for q in mlp.tensors()]
     origins = [(0, 0), (64, 64), (128, 0), (5, 190)]
-    kw = dict(noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=99, philox_offset=1)
+    kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=99, noise_offset=1)
     geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(32, 32), num_crops=4, **kw)
     y_all = fused.fused_forward(geo, fp[0].to(dev), fp[1].to(dev), origins, params)
     geo_b = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(32, 32), num_crops=2, sample_base=2 * 1024, **kw)
@@ -593,7 +593,7 @@ def test_training_trajectory_and_psnr(dev):
         inputs, coord, lod = O.random_crop_dataset([img], 256, 2, uniform, 0, 2)
         x = O.create_decoder_input(cur[0], cur[1], coord, (256, 256), 0.25, 0, 6)
         if epoch < cfg.NUM_EPOCHS * 0.95:
-            x = x + O.philox_noise(x.shape[0], 73, 8, seed=7, offset=epoch)
+            x = x + O.kernel_noise(x.shape[0], 73, 8, seed=7, offset=epoch)
         loss = torch.nn.functional.mse_loss(O.mlp_forward(x, mlp_ref), inputs.reshape(-1, 3))
         opt.zero_grad(); loss.backward(); opt.step(); sched.step()
         O.fp_quantize_clamp(cur, 0, 8)

@@ -162,7 +162,7 @@ def _oracle_step(geo, g0, g1, org, params, target, **kw):
     from neural_image_compression_v2_amd import fused
     from oracle import nic_oracle as O
     mlp = O.MLPParams([params[0], params[2], params[4]], [params[1], params[3], params[5]])
-    noise = O.philox_noise(geo.n_samples, geo.cin, geo.num_bits, geo.philox_seed, geo.philox_offset, geo.sample_base)
+    noise = O.kernel_noise(geo.n_samples, geo.cin, geo.num_bits, geo.noise_seed, geo.noise_offset, geo.sample_base)
     r = O.forward_backward(g0, g1, mlp, [tuple(int(v) for v in o) for o in org], geo.extent, geo.step_number, geo.mip_level, target, noise,
                            geo.pe_channels, method=geo.method, use_tri_pe=geo.use_tri_pe, mean_over=(geo.n_samples if geo.loss_scale is None else int(round(1 / (3 * geo.loss_scale)))))
     offs, sizes, total = fused.grad_bucket_layout(geo, g0, g1)
@@ -188,7 +188,7 @@ def _dp_worker(rank, world, port, out_path):
         mlp = O.init_mlp(73, 64, generator=g)
         origins = torch.tensor([[0, 0], [10, 20], [33, 7], [40, 40], [5, 48]])            # 5 crops over 2 ranks: 3 + 2
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(16, 16), num_crops=5,
-                                 noise_mode=_lib.NIC_NOISE_PHILOX, philox_seed=5, philox_offset=9)
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5, noise_offset=9)
         target = torch.rand(geo.n_samples, 3, generator=g)
         out = data_parallel_step(_oracle_step, geo, fp[0].detach(), fp[1].detach(), origins, mlp.tensors(), target)
         if rank == 0:

@@ -328,13 +328,24 @@ def test_philox_known_answers():
     assert [hex(v) for v in p] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
 
 
-def test_philox_noise_statistics():
-    n = O.philox_noise(4096, 73, 8, seed=7, offset=3)
+def test_threefry_known_answers():
+    # Random123 kat_vectors: threefry4x32-20
+    z = O.threefry4x32(np.zeros((1, 4), dtype=np.uint32), (0, 0, 0, 0), 20)[0]
+    assert [hex(v) for v in z] == ["0x9c6ca96a", "0xe17eae66", "0xfc10ecd4", "0x5256a7d8"]
+    f = O.threefry4x32(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint32), (0xFFFFFFFF,) * 4, 20)[0]
+    assert [hex(v) for v in f] == ["0x2a881696", "0x57012287", "0xf6c7446e", "0xa16a6732"]
+    p = O.threefry4x32(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], dtype=np.uint32),
+                       (0xa4093822, 0x299f31d0, 0x082efa98, 0xec4e6c89), 20)[0]
+    assert [hex(v) for v in p] == ["0x59cd1dbb", "0xb8879579", "0x86b5d00c", "0xac8b6d84"]
+
+
+def test_kernel_noise_statistics():
+    n = O.kernel_noise(4096, 73, 8, seed=7, offset=3)
     assert n.shape == (4096, 73) and n.dtype == torch.float32
     assert float(n.abs().max()) < 0.5 / 256
     assert abs(float(n.mean())) < 2e-5
     assert abs(float(n.var()) - (1 / 256) ** 2 / 12) < 1e-7
     # different offsets / seeds / sample bases give different streams; sample_base is a pure shift
-    assert not torch.equal(n, O.philox_noise(4096, 73, 8, seed=7, offset=4))
-    assert not torch.equal(n, O.philox_noise(4096, 73, 8, seed=8, offset=3))
-    assert torch.equal(n[100:200], O.philox_noise(100, 73, 8, seed=7, offset=3, sample_base=100))
+    assert not torch.equal(n, O.kernel_noise(4096, 73, 8, seed=7, offset=4))
+    assert not torch.equal(n, O.kernel_noise(4096, 73, 8, seed=8, offset=3))
+    assert torch.equal(n[100:200], O.kernel_noise(100, 73, 8, seed=7, offset=3, sample_base=100))
