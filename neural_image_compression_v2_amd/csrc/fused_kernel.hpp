@@ -497,10 +497,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
             int lc[3], tc[3];
             if (L::DIM == 2) {
-                lc[0] = pl / L::TY; lc[1] = pl % L::TY; lc[2] = 0;
+                lc[0] = pl % L::TX; lc[1] = pl / L::TX; lc[2] = 0;              // x fastest: x is the grids' contiguous axis
                 tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y; tc[2] = 0;
             } else {
-                lc[0] = pl / (L::TY * L::TZ); lc[1] = (pl / L::TZ) % L::TY; lc[2] = pl % L::TZ;
+                lc[0] = pl % L::TX; lc[1] = (pl / L::TX) % L::TY; lc[2] = pl / (L::TX * L::TY);
                 tc[2] = tt % p.tiles_z; tt /= p.tiles_z;
                 tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y;
             }

@@ -212,7 +212,7 @@ struct Layout2D {
     static constexpr int DIM = 2, K0 = 4, K1 = 4, CIN = 73;
     static constexpr int NSLOT = 40;   // 16 + 16 + 8  -> KPAD = 80
     static constexpr int NGRID = 30;   // 24 G0 (2 corners x 12 ch) + 6 G1 channels per half
-    static constexpr int TX = 4, TY = 8, TZ = 1;   // wave tile of 32 samples
+    static constexpr int TX = 16, TY = 2, TZ = 1;   // wave block of 32 G0 cells, lanes x-fastest (x = the grids' contiguous axis: 2 rows per gather / atomic)
     __host__ __device__ static constexpr int slot_channel(int s, int h) {
         if (s < 24) return 24 * h + s;                  // G0 corner 2h + s/12, channel s%12
         if (s < 30) return 48 + 6 * h + (s - 24);       // G1 channel 6h + ..
