@@ -609,7 +609,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 for (int to = 0; to < 2; ++to) {
                     const f32x4 a = ld4(&w1_row[32 * to * LD1 + col]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[to] = mfma32(a[j], xs[sig + j], z[to]);
+                    for (int j = 0; j < 4; ++j) {
+                        // a k-step whose slot is zero padding in BOTH lane halves contributes nothing: no MFMA
+                        if (L::slot_channel(sig + j, 0) == kSlotZero && L::slot_channel(sig + j, 1) == kSlotZero) continue;
+                        z[to] = mfma32(a[j], xs[sig + j], z[to]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
