@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpixels/s of one full training step (fused forward + backward, gradient exchange, Adam + clamp)
 on BASELINE.json's configs[1]: a 3840 x 2160 RGB fit, dense G0/G1 grid pair (reference semantics, no-mip),
-3 x Linear(64) decoder, in-kernel Philox noise - every pixel of the image once per step.
+3 x Linear(64) decoder, in-kernel Threefry noise - every pixel of the image once per step.
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
 
@@ -162,7 +162,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "3840x2160 RGB fit, every pixel once per step: dense G0 [12,961,541] + G1 [12,481,271] grid pair "
-                                   "(reference semantics, no-mip), triangular PE, 3xLinear(64) GELU decoder, Philox noise, MSE, "
+                                   "(reference semantics, no-mip), triangular PE, 3xLinear(64) GELU decoder, in-kernel Threefry-4x32-12 noise, MSE, "
                                    "fused fwd+bwd + grad all-reduce + Adam + clamp",
                        "pixels_per_step_per_gpu": n_local, "parallelism": f"dp{world} (sample-sharded, replicated parameters)",
                        "final_loss": round(loss, 6)},
