@@ -12,7 +12,7 @@ dec = ColorDecoder(73, 64).to(dev)
 params = [p.detach() for p in dec.linear_params()]
 target = torch.rand(H * W, 3, device=dev)
 geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
-                         noise_mode=int(os.environ.get("NOISE", "2")), philox_seed=7, philox_offset=1)
+                         noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1)
 org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
 for _ in range(3):
     out = fused.fused_forward_backward(geo, fp[0].detach(), fp[1].detach(), org, params, target)

@@ -389,6 +389,33 @@ __device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, cons
     }
 }
 
+// The 2^D G0 cells inside one G1 cell sit in 2^D lanes of the wave and would hit the same G1 nodes in the same atomic
+// instruction (same-address atomics of one instruction serialise in L2: measured, the G1 half of the flush cost 2.4x the G0
+// half).  They are summed across lanes first - partner = the lane whose block coordinate differs in the last bit along one
+// axis, when it is inside the wave's block and really has the same G1 cell (clamped cells, odd alignment) - and only the
+// even-coordinate lane keeps the sum; the others are left with exact zeros, which the flush skips.
+template <class L>
+__device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, const int (&blk)[3], int lane) {
+    constexpr int D = L::DIM;
+    constexpr int T[3] = {L::TX, L::TY, L::TZ};
+    constexpr int STR[3] = {1, L::TX, L::TX * L::TY};
+    const int pl = lane & 31;
+    const int lc[3] = {pl % L::TX, (pl / L::TX) % L::TY, pl / (L::TX * L::TY)};
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        const bool odd = blk[a] & 1;
+        const int pc = lc[a] + (odd ? -1 : 1);
+        const bool inb = pc >= 0 && pc < T[a];
+        const int partner = inb ? lane + (odd ? -STR[a] : STR[a]) : lane;
+        const bool pair = inb && (uint32_t)__shfl((int)off1, partner) == off1;
+#pragma unroll
+        for (int i = 0; i < GridAcc<L>::K1 * (kC / 2); ++i) {
+            const float pv = __shfl(ga.g1[i], partner);
+            ga.g1[i] = pair ? (odd ? 0.f : ga.g1[i] + pv) : ga.g1[i];
+        }
+    }
+}
+
 // one fp32 atomic per (corner, channel) of the lane's cell; exact zeros (cells outside the crop, zero weights) are skipped
 template <class L>
 __device__ __forceinline__ void flush_grid_grads(const FusedParams& p, uint32_t off0, uint32_t off1, int h, const GridAcc<L>& ga) {
@@ -575,6 +602,14 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             n = valid ? n : p.n_total - 1;
         }
 
+        // ---------- the sample's target (or incoming dY): fetched now, used after the forward pass.  n is a valid sample index
+        // for every lane (masked lanes are clamped), so the loads are unconditional and all in flight together
+        float tgt[3] = {0.f, 0.f, 0.f};
+        if (TRAIN) {
+            const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
+        }
         // ---------- input slots
         float xs[L::NSLOT];
         EncCtx cx;
@@ -601,19 +636,24 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 a1[2], d1[2];
         {
             f32x16 z[2] = {f32x16(0.f), f32x16(0.f)};
+            // every MFMA phase fetches its LDS operands one step (4 MFMAs) ahead, so the LDS latency of step i + 1 runs
+            // under the MFMAs of step i instead of in front of them
+            constexpr int NST = 2 * (L::NSLOT / 4);                     // step = (4 slots, one row tile)
+            auto w1_at = [&](int st) {
+                const int sig = 4 * (st >> 1);
+                return ld4(&w1_row[32 * (st & 1) * LD1 + 32 * (sig >> 4) + 8 * ((sig & 15) >> 2)]);
+            };
+            f32x4 aq[2];
+            aq[0] = w1_at(0);
 #pragma unroll
-            for (int s4 = 0; s4 < L::NSLOT / 4; ++s4) {
-                const int sig = 4 * s4;
-                const int col = 32 * (sig >> 4) + 8 * ((sig & 15) >> 2);
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) aq[(st + 1) & 1] = w1_at(st + 1);
+                const int sig = 4 * (st >> 1), to = st & 1;
 #pragma unroll
-                for (int to = 0; to < 2; ++to) {
-                    const f32x4 a = ld4(&w1_row[32 * to * LD1 + col]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // a k-step whose slot is zero padding in BOTH lane halves contributes nothing: no MFMA
-                        if (L::slot_channel(sig + j, 0) == kSlotZero && L::slot_channel(sig + j, 1) == kSlotZero) continue;
-                        z[to] = mfma32(a[j], xs[sig + j], z[to]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    // a k-step whose slot is zero padding in BOTH lane halves contributes nothing: no MFMA
+                    if (L::slot_channel(sig + j, 0) == kSlotZero && L::slot_channel(sig + j, 1) == kSlotZero) continue;
+                    z[to] = mfma32(aq[st & 1][j], xs[sig + j], z[to]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -641,19 +681,17 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[to][4 * r4 + j] = bb[j];
                 }
+            auto w2_at = [&](int st) { return ld4(&w2_row[32 * (st & 1) * LD2 + 32 * (st >> 3) + 8 * ((st >> 1) & 3)]); };
+            f32x4 aq[2];
+            aq[0] = w2_at(0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int st = 0; st < 16; ++st) {                            // step = (t, r4, to)
+                if (st + 1 < 16) aq[(st + 1) & 1] = w2_at(st + 1);
+                const int t = st >> 3, r4 = (st >> 1) & 3, to = st & 1;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int col = 32 * t + 8 * r4;
-#pragma unroll
-                    for (int to = 0; to < 2; ++to) {
-                        const f32x4 a = ld4(&w2_row[32 * to * LD2 + col]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) z[to] = mfma32(a[j], a1[t][4 * r4 + j], z[to]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int j = 0; j < 4; ++j) z[to] = mfma32(aq[st & 1][j], a1[t][4 * r4 + j], z[to]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int to = 0; to < 2; ++to)
 #pragma unroll
@@ -702,11 +740,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             for (int c = 0; c < 3; ++c) {
                 float g;
                 if (MODE == MODE_TRAIN_MSE) {
-                    const float diff = own ? yv[c] - p.target[n * 3 + c] : 0.f;
+                    const float diff = own ? yv[c] - tgt[c] : 0.f;
                     accLoss += diff * diff;
                     g = p.grad_scale * diff;
                 } else {
-                    g = own ? p.dy[n * 3 + c] : 0.f;
+                    g = own ? tgt[c] : 0.f;
                 }
                 dz3[c] = g * yv[c] * (1.0f - yv[c]);
                 accB3[c] += dz3[c];
@@ -771,15 +809,17 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         {
             lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to2 * LDT);
             lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk2 * LDT);
+            f32x4 aq[2], bq[2];
+            aq[0] = ld4(&sa_o[0]);
+            bq[0] = ld4(&sb_o[0]);
 #pragma unroll
-            for (int src = 0; src < 4; ++src) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 a = ld4(&sa_o[src * S::SCR_PER_WAVE + 4 * g]);
-                    const f32x4 b = ld4(&sb_o[src * S::SCR_PER_WAVE + 4 * g]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) accW2o = mfma32(a[j], b[j], accW2o);
+            for (int st = 0; st < 16; ++st) {                            // step = (source wave, 4 samples)
+                if (st + 1 < 16) {
+                    aq[(st + 1) & 1] = ld4(&sa_o[((st + 1) >> 2) * S::SCR_PER_WAVE + 4 * ((st + 1) & 3)]);
+                    bq[(st + 1) & 1] = ld4(&sb_o[((st + 1) >> 2) * S::SCR_PER_WAVE + 4 * ((st + 1) & 3)]);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accW2o = mfma32(aq[st & 1][j], bq[st & 1][j], accW2o);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -791,15 +831,31 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 dz1[2];
         {
             f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
+            // A operands (columns of W2) are fetched one step (2 k-steps = 4 MFMAs) ahead: the LDS latency of step i + 1
+            // runs under the MFMAs of step i instead of in front of them
+            float wq[2][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = 32 * t + ROWC(r);
+                for (int tk = 0; tk < 2; ++tk) wq[0][2 * u + tk] = w2_col[ROWC(u) * LD2 + 32 * tk];
 #pragma unroll
-                    for (int tk = 0; tk < 2; ++tk) acc[tk] = mfma32(w2_col[o * LD2 + 32 * tk], dz2[t][r], acc[tk]);
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int st = 0; st < 16; ++st) {
+                if (st + 1 < 16) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int rr = 2 * (st + 1) + u, o = 32 * (rr >> 4) + ROWC(rr & 15);
+#pragma unroll
+                        for (int tk = 0; tk < 2; ++tk) wq[(st + 1) & 1][2 * u + tk] = w2_col[o * LD2 + 32 * tk];
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rr = 2 * st + u;
+#pragma unroll
+                    for (int tk = 0; tk < 2; ++tk) acc[tk] = mfma32(wq[st & 1][2 * u + tk], dz2[rr >> 4][rr & 15], acc[tk]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             dz1[0] = acc[0] * d1[0];
             dz1[1] = acc[1] * d1[1];
         }
@@ -818,15 +874,17 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             lds_cf* const xi_o = opaque(sm + S::OFF_XIMG + pl * LDT + 16 * h + 32 * tk1 * LDT);
 #pragma unroll
             for (int c2 = 0; c2 < NCH; ++c2) {
+                f32x4 aq[2], bq[2];
+                aq[0] = ld4(&sa_o[0]);
+                bq[0] = ld4(&xi_o[64 * c2 * LDT]);
 #pragma unroll
-                for (int src = 0; src < 4; ++src) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 a = ld4(&sa_o[src * S::SCR_PER_WAVE + 4 * g]);
-                        const f32x4 b = ld4(&xi_o[src * S::XIMG_PER_WAVE + 64 * c2 * LDT + 4 * g]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) accW1o[c2] = mfma32(a[j], b[j], accW1o[c2]);
+                for (int st = 0; st < 16; ++st) {
+                    if (st + 1 < 16) {
+                        aq[(st + 1) & 1] = ld4(&sa_o[((st + 1) >> 2) * S::SCR_PER_WAVE + 4 * ((st + 1) & 3)]);
+                        bq[(st + 1) & 1] = ld4(&xi_o[((st + 1) >> 2) * S::XIMG_PER_WAVE + 64 * c2 * LDT + 4 * ((st + 1) & 3)]);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accW1o[c2] = mfma32(aq[st & 1][j], bq[st & 1][j], accW1o[c2]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -902,15 +960,30 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 dxacc[NGT];
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
+            // same one-step-ahead operand fetch as dA1
+            float wq[2][2 * NGT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = 32 * t + ROWC(r);
+                for (int tg = 0; tg < NGT; ++tg) wq[0][NGT * u + tg] = w1_col[ROWC(u) * LD1 + 32 * tg];
 #pragma unroll
-                    for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma32(w1_col[o * LD1 + 32 * tg], dz1[t][r], dxacc[tg]);
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int st = 0; st < 16; ++st) {
+                if (st + 1 < 16) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int rr = 2 * (st + 1) + u, o = 32 * (rr >> 4) + ROWC(rr & 15);
+#pragma unroll
+                        for (int tg = 0; tg < NGT; ++tg) wq[(st + 1) & 1][NGT * u + tg] = w1_col[o * LD1 + 32 * tg];
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rr = 2 * st + u;
+#pragma unroll
+                    for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma32(wq[st & 1][NGT * u + tg], dz1[rr >> 4][rr & 15], dxacc[tg]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (SRC == SRC_ENCODE) {
                 accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc);        // masked lanes carry exact zeros (dZ3 = 0)
             } else if (valid) {
@@ -924,7 +997,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
-        if (SRC == SRC_ENCODE && TRAIN && !(p.d.reserved & 1)) flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+        if (SRC == SRC_ENCODE && TRAIN && !(p.d.reserved & 1)) {
+            combine_g1_lanes<L>(gacc, blk_off1, blk, lane);
+            flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+        }
         STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
 #ifdef NIC_STAMPS
