@@ -322,22 +322,24 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
         }
         return;
     }
-    constexpr int NG0 = L::K0 / 2 * kC;              // multiple of 8: the G0 slots of a half are whole blocks
-    static_assert(NG0 % 8 == 0, "G0 slots must cover whole Philox blocks");
+    constexpr int NG0 = L::K0 / 2 * kC;              // G0 slots of a half = one channel group (see noise_block)
+    constexpr int GB = (NG0 + 15) / 16;              // blocks per G0 group
 #pragma unroll
-    for (int j = 0; j < NG0 / 8; ++j) {
-        const U4 b = noise_block(ns, sample_global, NG0 / 8 * h + j);
+    for (int j = 0; j < GB; ++j) {
+        const U4 b = noise_block(ns, sample_global, GB * h + j);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) xs[8 * j + t] += noise_from_block(ns, b, t);
+        for (int t = 0; t < 16; ++t)
+            if (16 * j + t < NG0) xs[16 * j + t] += noise_from_block(ns, b, t);
     }
-    constexpr int RB0 = L::K0 * kC / 8;              // first block of the non-G0 channels
-    static_assert((L::CIN - 1) / 8 - RB0 <= 3, "rest channels span at most 4 blocks");
-    // The remaining slots' channels depend on the lane-half, but for EACH half (block, word, 16-bit half) of a slot are
+    constexpr int RB0 = 2 * GB;                      // first block of the non-G0 channels
+    constexpr int NREST = L::CIN - L::K0 * kC;
+    constexpr int NRB = (NREST + 15) / 16;
+    // The remaining slots' channels depend on the lane-half, but for EACH half (block, word, byte) of a slot are
     // compile-time constants: pick both candidates with constant indices and select by h - one v_cndmask per slot, no
     // branches (a runtime channel index compiles to a divergent branch per slot and block: ~6K cycles per round).
-    uint32_t rw[4][4];
+    uint32_t rw[NRB][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NRB; ++j) {
         const U4 b = noise_block(ns, sample_global, RB0 + j);
         rw[j][0] = b.x; rw[j][1] = b.y; rw[j][2] = b.z; rw[j][3] = b.w;
     }
@@ -345,13 +347,11 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
     for (int s = NG0; s < L::NSLOT; ++s) {
         const int ch0 = L::slot_channel(s, 0), ch1 = L::slot_channel(s, 1);
         if (ch0 < 0 && ch1 < 0) continue;
-        uint32_t u0 = 0, u1 = 0;
-        if (ch0 >= 0) { const uint32_t w = rw[(ch0 >> 3) - RB0][(ch0 >> 1) & 3]; u0 = (ch0 & 1) ? (w >> 16) : (w & 0xFFFFu); }
-        if (ch1 >= 0) { const uint32_t w = rw[(ch1 >> 3) - RB0][(ch1 >> 1) & 3]; u1 = (ch1 & 1) ? (w >> 16) : (w & 0xFFFFu); }
-        const uint32_t u = h ? u1 : u0;
-        const float nzv = (((float)u + 0.5f) * (1.0f / 65536.0f) - 0.5f) * ns.scale;
-        const bool has = h ? (ch1 >= 0) : (ch0 >= 0);
-        xs[s] += has ? nzv : 0.f;
+        const int i0 = ch0 - L::K0 * kC, i1 = ch1 - L::K0 * kC;       // index among the non-G0 channels
+        float n0 = 0.f, n1 = 0.f;
+        if (ch0 >= 0) n0 = noise_from_byte(ns, rw[i0 >> 4][(i0 >> 2) & 3], i0 & 3);
+        if (ch1 >= 0) n1 = noise_from_byte(ns, rw[i1 >> 4][(i1 >> 2) & 3], i1 & 3);
+        xs[s] += h ? n1 : n0;
     }
 }
 

@@ -162,16 +162,22 @@ struct NoiseSrc {
     float scale;            // 2^-num_bits
 };
 
-// one generator block = 8 channels (4 words x 2 halves) of one sample
+// One generator block = 16 noise values (4 words x 4 bytes) of one sample: value i of a block is byte i & 3 of word i >> 2,
+// u8 -> ((u8 + 1/2) / 256 - 1/2) * 2^-bits (uniform on a 2^-8 lattice of the quantisation step, zero mean).
+// Block numbering of a sample (restated in oracle/nic_oracle.py::kernel_noise): the G0 channels come in two groups of
+// NG0 = K0/2 * C channels (the corners with dx = 0, then dx = 1 - the two lane halves of the fused kernel), each group
+// starting a new block; the remaining channels (G1, PE, LOD) follow in blocks of their own.
 __device__ __forceinline__ U4 noise_block(const NoiseSrc& ns, uint64_t sample, int blk) {
     U4 c{(uint32_t)sample, (uint32_t)blk + ((uint32_t)(sample >> 32) << 8), ns.off_lo, ns.off_hi};
     return threefry4x32_12(c, ns.k0, ns.k1, 0x4E494332u /* "NIC2" */, 0u);
 }
-__device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& b, int ch) {
-    const int w = (ch >> 1) & 3;
-    const uint32_t word = w == 0 ? b.x : (w == 1 ? b.y : (w == 2 ? b.z : b.w));
-    const uint32_t u16 = (ch & 1) ? (word >> 16) : (word & 0xFFFFu);
-    return (((float)u16 + 0.5f) * (1.0f / 65536.0f) - 0.5f) * ns.scale;
+__device__ __forceinline__ uint32_t block_word(const U4& b, int w) { return w == 0 ? b.x : (w == 1 ? b.y : (w == 2 ? b.z : b.w)); }
+__device__ __forceinline__ float noise_from_byte(const NoiseSrc& ns, uint32_t word, int byte) {
+    const float u8 = (float)((word >> (8 * byte)) & 0xFFu);                     // v_cvt_f32_ubyteN
+    return ((u8 + 0.5f) * (1.0f / 256.0f) - 0.5f) * ns.scale;
+}
+__device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& b, int i) {
+    return noise_from_byte(ns, block_word(b, (i >> 2) & 3), i & 3);
 }
 
 // ---------------------------------------------------------------------------------------------------
