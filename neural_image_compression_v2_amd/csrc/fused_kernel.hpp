@@ -82,12 +82,20 @@ struct Lds {
     // (KT odd: 2D and method 4) is contracted by every wave over its own samples only ("partial" tiles, summed later).
     static constexpr int KTF = KT & ~1;                       // dW1 col tiles handled in cross-wave chunks of two
     static constexpr int PART = KT & 1;
-    static constexpr int NSLOT_REC = NACC + (PART ? 8 : 0);   // + [4 waves][2 row tiles] partial tiles
+    // When the odd col tile holds at most 16 real rows (2D: rho 64..79) it is contracted with 16x16x4 MFMAs - 4 row tiles of
+    // [16 o][16 rho], half the matrix-pipe time of two 32x32 tiles that are half padding, and 16 accumulator registers
+    // instead of 32.
+    static constexpr bool PART16 = PART && XIMG && (KPAD - 32 * (KT - 1) <= 16);
+    static constexpr int NSLOT_REC = NACC + (PART ? (PART16 ? 4 : 8) : 0);   // + per-wave partial tiles: [4][1024] or [4][2][1024]
     static constexpr int REC = NSLOT_REC * 1024 + 4 * 320;    // floats per WORKGROUP record; tails per wave: db2, dW3, db3, loss
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// 16x16x4: A row / B col = lane & 15, k = lane >> 4; D register r of lane l = row 4 (l >> 4) + r, col l & 15
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 // LDS traffic between lanes of ONE wave: DS operations of a wave complete in order, so only the
 // compiler has to be kept from moving accesses across this point.
@@ -498,6 +506,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     f32x16 accW2o = f32x16(0.f);                                // dW2 tile (to = wave >> 1, tk = wave & 1)
     f32x16 accW1o[NCH > 0 ? NCH : 1];                           // dW1 tiles (to = wave & 1, tk = 2c + (wave >> 1))
     f32x16 accW1p[2];                                           // partial dW1 tiles (to = 0, 1; tk = KT - 1), own samples
+    f32x4 accW1q[4];                                            // PART16: the same as 4 row tiles of 16 x 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accW1q[i] = f32x4(0.f);
 #pragma unroll
     for (int c = 0; c < (NCH > 0 ? NCH : 1); ++c) accW1o[c] = f32x16(0.f);
     accW1p[0] = accW1p[1] = f32x16(0.f);
@@ -888,7 +899,26 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (S::PART) {
+            if (S::PART16) {
+                // odd last col tile, 16 real rows: 4 row tiles of 16x16x4 over this wave's own samples; lane (i, kg) feeds
+                // row / col i with samples 8 kg + j for MFMA j
+                const int i16 = lane & 15, kg = lane >> 4;
+                lds_cf* const xi_q = opaque(sm + S::OFF_XIMG + wave * S::XIMG_PER_WAVE + (32 * (KT - 1) + i16) * LDT + 8 * kg);
+                lds_cf* const sa_q = opaque(SA + i16 * LDT + 8 * kg);
+                f32x4 bq2[2], aq2[4][2];
+                bq2[0] = ld4(&xi_q[0]);
+                bq2[1] = ld4(&xi_q[4]);
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    aq2[ot][0] = ld4(&sa_q[16 * ot * LDT]);
+                    aq2[ot][1] = ld4(&sa_q[16 * ot * LDT + 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int ot = 0; ot < 4; ++ot) accW1q[ot] = mfma16(aq2[ot][j >> 2][j & 3], bq2[j >> 2][j & 3], accW1q[ot]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (S::PART) {
                 // odd last col tile: both row tiles over this wave's own samples
                 constexpr int ROWS_LAST = S::KPAD - 32 * (KT - 1);         // lanes past the image re-read a valid row: their columns
                 const int prow = pl < ROWS_LAST ? pl : pl - ROWS_LAST;     // (rho >= KPAD) are discarded by the reduction
@@ -1024,7 +1054,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) rec[(a1i * 16 + r) * 64 + lane] = accW1o[c][r];
         }
-        if (S::PART) {
+        if (S::PART16) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[(S::NACC + wave) * 1024 + (ot * 4 + r) * 64 + lane] = accW1q[ot][r];
+        } else if (S::PART) {
 #pragma unroll
             for (int to = 0; to < 2; ++to)
 #pragma unroll
@@ -1057,7 +1092,16 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
     if (gid < S::NACC * 1024) {
         const int a = gid >> 10;
         if (S::PART && a < 2 * KT && a % KT == KT - 1) {          // dW1 tile (to, KT-1): 4 per-wave partials
-            nsrc = 4; off0 = (S::NACC + a / KT) * 1024 + (gid & 1023); stride = 2 * 1024;
+            if (S::PART16) {
+                // element (o, rho = 32 (KT-1) + col) of the 16x16 tiles: tile o >> 4, D register o & 3 of lane 16 ((o & 15) >> 2) + col
+                const int r = (gid >> 6) & 15, ln = gid & 63;
+                const int o = 32 * (a / KT) + ROW(r, ln >> 5), col = ln & 31;
+                nsrc = col < 16 ? 4 : 0;
+                off0 = S::NACC * 1024 + ((o >> 4) * 4 + (o & 3)) * 64 + 16 * ((o & 15) >> 2) + (col & 15);
+                stride = 1024;
+            } else {
+                nsrc = 4; off0 = (S::NACC + a / KT) * 1024 + (gid & 1023); stride = 2 * 1024;
+            }
         }
     } else {
         nsrc = 4; off0 = S::NSLOT_REC * 1024 + (gid - S::NACC * 1024); stride = 320;
