@@ -671,12 +671,15 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int to = 0; to < 2; ++to)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float a, d;
-                    if (TRAIN) gelu_and_grad(z[to][r], a, d);
-                    else { a = gelu_only(z[to][r]); d = 0.f; }
-                    a1[to][r] = a;
-                    d1[to][r] = d;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
+                    f32x4_t aq4, dq4;
+                    gelu_and_grad4(zq, aq4, dq4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a1[to][4 * r4 + j] = aq4[j];
+                        d1[to][4 * r4 + j] = TRAIN ? dq4[j] : 0.f;
+                    }
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -706,12 +709,15 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int to = 0; to < 2; ++to)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float a, d;
-                    if (TRAIN) gelu_and_grad(z[to][r], a, d);
-                    else { a = gelu_only(z[to][r]); d = 0.f; }
-                    a2[to][r] = a;
-                    d2[to][r] = d;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
+                    f32x4_t aq4, dq4;
+                    gelu_and_grad4(zq, aq4, dq4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a2[to][4 * r4 + j] = aq4[j];
+                        d2[to][4 * r4 + j] = TRAIN ? dq4[j] : 0.f;
+                    }
                 }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -120,6 +120,45 @@ __device__ __forceinline__ void gelu_and_grad(float z, float& a, float& d) {
     a = z * cdf;
     d = fmaf(z * 0.39894228040143267794f, ex, cdf);
 }
+// Four evaluations at once, written as two interleaved packed-fp32 chains: a dependent v_pk_fma_f32 -> v_pk_fma_f32 pair costs
+// a wait state (s_nop) when issued back to back, the second chain fills those slots.  Same arithmetic as gelu_and_grad except
+// that exp(-z^2/2) is taken as exp2(z * (z * (-log2(e)/2))): one multiply fewer.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_and_grad4(const f32x4_t z, f32x4_t& a, f32x4_t& d) {
+    const f32x2 za = {z[0], z[1]}, zb = {z[2], z[3]};
+    constexpr float kP = 0.3275911f * 0.70710678118654752440f, kE = -0.5f * 1.44269504088896340736f;
+    f32x2 ta, tb, ea, eb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ta[i] = __builtin_amdgcn_rcpf(fmaf(kP, fabsf(za[i]), 1.0f));
+        tb[i] = __builtin_amdgcn_rcpf(fmaf(kP, fabsf(zb[i]), 1.0f));
+        ea[i] = __builtin_amdgcn_exp2f(za[i] * (za[i] * kE));
+        eb[i] = __builtin_amdgcn_exp2f(zb[i] * (zb[i] * kE));
+    }
+    f32x2 pa = pk_fma(f32x2(1.061405429f), ta, f32x2(-1.453152027f));
+    f32x2 pb = pk_fma(f32x2(1.061405429f), tb, f32x2(-1.453152027f));
+    pa = pk_fma(pa, ta, f32x2(1.421413741f));
+    pb = pk_fma(pb, tb, f32x2(1.421413741f));
+    pa = pk_fma(pa, ta, f32x2(-0.284496736f));
+    pb = pk_fma(pb, tb, f32x2(-0.284496736f));
+    pa = pk_fma(pa, ta, f32x2(0.254829592f));
+    pb = pk_fma(pb, tb, f32x2(0.254829592f));
+    pa = pa * ta;
+    pb = pb * tb;
+    const f32x2 ha = (pa * f32x2(0.5f)) * ea, hb = (pb * f32x2(0.5f)) * eb;       // (1 - erf(|u|)) / 2
+    f32x2 ca, cb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ca[i] = za[i] >= 0.f ? 1.0f - ha[i] : ha[i];
+        cb[i] = zb[i] >= 0.f ? 1.0f - hb[i] : hb[i];
+    }
+    const f32x2 aa = za * ca, ab = zb * cb;
+    const f32x2 da = pk_fma(za * f32x2(0.39894228040143267794f), ea, ca), db = pk_fma(zb * f32x2(0.39894228040143267794f), eb, cb);
+    a = f32x4_t{aa[0], aa[1], ab[0], ab[1]};
+    d = f32x4_t{da[0], da[1], db[0], db[1]};
+}
 __device__ __forceinline__ float gelu_only(float z) {
     float a, d;
     gelu_and_grad(z, a, d);
