@@ -109,6 +109,7 @@ def main():
     total_steps = args.warmup + args.steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     stream = _lib.stream_ptr(dev)
+    adam_tab = (_lib.NicAdamTensor * len(tensors))()
 
     def step(i, events=None):
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
@@ -120,8 +121,8 @@ def main():
         grads = out.grad_mlp + [out.grad_g0, out.grad_g1]
         for k, (p, g, m, v) in enumerate(zip(tensors, grads, m_state, v_state)):
             lo, hi = (q_lo, 0.5) if k >= 6 else (1.0, -1.0)           # fp_quantize_clamp on the grids only
-            _lib.check(lib.nic_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), lrs[k] * cos, 0.9, 0.999, 1e-8,
-                                         i + 1, lo, hi, stream), "nic_adam_step")
+            adam_tab[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), i + 1, lrs[k] * cos, lo, hi, 0)
+        _lib.check(lib.nic_adam_multi(adam_tab, len(tensors), 0.9, 0.999, 1e-8, stream), "nic_adam_multi")   # Adam + clamp: one launch
         return out
 
     for i in range(args.warmup):

@@ -184,6 +184,25 @@ int nic_psnr(const float *a, const float *b, int64_t n, int num_bits, float *out
 int nic_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int64_t step, float clamp_lo, float clamp_hi, void *stream);
 
+/* ---- the whole optimiser step in ONE launch: Adam for every listed tensor - grids at lr 0.01, decoder
+ *      at lr 0.005, each already scaled by the caller's CosineAnnealingLR factor - with the fp_quantize_clamp of the grids
+ *      folded in (image_compression.py:266-269, 361-365; fp_def.py:227-232).  torch keeps one step counter per parameter
+ *      (a parameter whose .grad is None is skipped and does not advance), hence `step` per tensor.  The tensor table is
+ *      read on the host and passed to the kernel by value: at most NIC_ADAM_MAX_TENSORS per call. */
+#define NIC_ADAM_MAX_TENSORS 32
+typedef struct nic_adam_tensor {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t n;
+    int64_t step;            /* 1-based step count of THIS tensor */
+    float lr;
+    float clamp_lo, clamp_hi; /* clamp_lo > clamp_hi: no clamp */
+    int32_t reserved;
+} nic_adam_tensor;
+int nic_adam_multi(const nic_adam_tensor *tensors, int count, float beta1, float beta2, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,16 @@ class NicMlpGrads(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3)]
 
 
+NIC_ADAM_MAX_TENSORS = 32
+
+
+class NicAdamTensor(ctypes.Structure):
+    """struct nic_adam_tensor (include/nicv2_hip.h)."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_float), ("clamp_lo", ctypes.c_float),
+                ("clamp_hi", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _D = ctypes.POINTER(NicPathDesc)
 _M = ctypes.POINTER(NicMlp)
@@ -71,6 +81,7 @@ SIGNATURES = {
     "nic_psnr": (_I, [_P, _P, _L, _I, _P, _P, _SZ, _P]),
     "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _F, _P]),
     "nic_gather_corners": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P]),
+    "nic_adam_multi": (_I, [ctypes.POINTER(NicAdamTensor), _I, _F, _F, _F, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -275,6 +275,55 @@ __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, flo
     }
 }
 
+// Multi-tensor form: one launch for the whole parameter list.  A block owns a contiguous 4096-element chunk of one tensor
+// (found by walking the short prefix table), float4 where the chunk is 16-byte aligned in all four arrays.
+struct AdamEntry {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float step_size, bc2_sqrt, lo, hi;
+    int first_block;
+};
+struct AdamTable {
+    AdamEntry e[NIC_ADAM_MAX_TENSORS];
+    int count;
+    float b1, b2, eps;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                         float lo, float hi) {
+    m = m + (g - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    float x = p - step_size * (m / denom);
+    if (lo <= hi) x = fminf(fmaxf(x, lo), hi);
+    p = x;
+}
+constexpr int kAdamChunk = 4096;
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.e[k + 1].first_block) ++k;
+    const AdamEntry e = t.e[k];
+    const int64_t base = (int64_t)((int)blockIdx.x - e.first_block) * kAdamChunk;
+    const int64_t left = e.n - base;
+    const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
+    float* p = e.p + base; const float* g = e.g + base; float* m = e.m + base; float* v = e.v + base;
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    if (vec) {
+        const int n4 = cnt >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+            const float4 gg = reinterpret_cast<const float4*>(g)[i];
+            adam_one(pp.x, gg.x, mm.x, vv.x, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.y, gg.y, mm.y, vv.y, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.z, gg.z, mm.z, vv.z, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.w, gg.w, mm.w, vv.w, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        }
+        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+    }
+}
+
 static inline int blocks_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -467,6 +516,36 @@ int nic_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, (float)bc1, (float)sqrt(bc2), clamp_lo, clamp_hi);
+    return (int)hipGetLastError();
+}
+
+int nic_adam_multi(const nic_adam_tensor* tensors, int count, float beta1, float beta2, float eps, void* stream) {
+    if (count == 0) return NIC_OK;
+    if (!tensors) return NIC_E_NULL;
+    if (count < 0 || count > NIC_ADAM_MAX_TENSORS) return NIC_E_ARG;
+    AdamTable t;
+    t.b1 = beta1; t.b2 = beta2; t.eps = eps;
+    int nt = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const nic_adam_tensor& a = tensors[i];
+        if (a.n == 0) continue;
+        if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) return NIC_E_NULL;
+        if (a.n < 0 || a.step < 1) return NIC_E_ARG;
+        const double bc1 = 1.0 - pow((double)beta1, (double)a.step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)a.step);
+        AdamEntry& e = t.e[nt++];
+        e.p = a.param; e.g = a.grad; e.m = a.exp_avg; e.v = a.exp_avg_sq; e.n = a.n;
+        e.step_size = a.lr / (float)bc1;          // same roundings as nic_adam_step: (float) bias corrections, fp32 division in-kernel there
+        e.bc2_sqrt = (float)sqrt(bc2);
+        e.lo = a.clamp_lo; e.hi = a.clamp_hi;
+        e.first_block = (int)blocks;
+        blocks += (a.n + kAdamChunk - 1) / kAdamChunk;
+        if (blocks > 0x7fffffff) return NIC_E_ARG;
+    }
+    if (nt == 0) return NIC_OK;
+    t.count = nt;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }
 

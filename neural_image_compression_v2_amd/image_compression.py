@@ -21,6 +21,7 @@ from . import _lib, fused
 from .fp_def import (create_pyramid, create_pyramid_3d, create_pyramid_mip_levels, fp_all_quantize, fp_freeze,
                      fp_quantize_clamp)
 from .models import quantize_to_bit
+from .optim import FusedAdam
 from .utils import calculate_psnr
 from .var2 import Settings
 
@@ -64,8 +65,10 @@ class ImageCompression:
         self.feature_pyramid, self.feature_pyramid_levels = pyr(c.FEATURE_PYRAMID_SIZE, c.FEATURE_PYRAMID_CHANNELS, c.FP_BITS,
                                                                  self.device, torch.float32, c.TF_NO_MIP)    # :352-357
         self.feature_pyramid_mip_levels_dict = create_pyramid_mip_levels(c.IMAGE_SIZE, c.FEATURE_PYRAMID_SIZE)  # :360
-        self.optimizer = torch.optim.Adam([{"params": self.feature_pyramid, "lr": 0.01},
-                                           {"params": self.decoder.parameters(), "lr": 0.005}])            # :361-364
+        # Adam + the grids' clamp in one launch per step (optim.FusedAdam; state layout of torch.optim.Adam)
+        self.optimizer = FusedAdam([{"params": self.feature_pyramid, "lr": 0.01},
+                                    {"params": self.decoder.parameters(), "lr": 0.005}])                   # :361-364
+        self.optimizer.set_clamp(self.feature_pyramid, -(2 ** c.FP_BITS - 1) / 2 ** (c.FP_BITS + 1), 0.5)  # fp_def.py:227-232
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365
         self.images: List[torch.Tensor] = []
         self.loss_history: List[torch.Tensor] = []
@@ -170,9 +173,10 @@ class ImageCompression:
             loss = ((y - target) ** 2).mean()                                                          # nn.MSELoss (:259)
             self.optimizer.zero_grad()
             loss.backward()
-        self.optimizer.step()
+        self.optimizer.step()                             # Adam of both groups + the clamp of :269, one launch
         self.scheduler.step()
-        fp_quantize_clamp(fp, fl, c.FP_BITS)                                                           # :269
+        if not isinstance(self.optimizer, FusedAdam):
+            fp_quantize_clamp(fp, fl, c.FP_BITS)                                                       # :269
         return loss.detach()
 
     def _uniform(self) -> bool:

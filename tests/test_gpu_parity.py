@@ -471,6 +471,44 @@ def test_adam_kernel_matches_torch(dev):
     assert float(pd.max()) <= np.float32(0.1) and float(pd.min()) >= -np.float32(0.1)
 
 
+def test_fused_adam_matches_torch_adam_with_cosine_and_clamp(dev):
+    """FusedAdam (one nic_adam_multi launch per step: two lr groups, per-parameter step counts, parameters without a gradient
+    skipped, clamp folded in) against torch.optim.Adam + CosineAnnealingLR + clamp_ on the CPU (image_compression.py:266-269,
+    361-365); odd sizes exercise the unaligned tail and the multi-chunk block table."""
+    from neural_image_compression_v2_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(12, 33, 31), (12, 17, 15), (64, 73), (64,), (64, 64), (64,), (3, 64), (3,), (9001,)]
+    ref = [(torch.rand(*sh, generator=g) - 0.5).requires_grad_(True) for sh in shapes]
+    prod = [r.detach().clone().to(dev).requires_grad_(True) for r in ref]
+    steps = 12
+    o_ref = torch.optim.Adam([{"params": ref[:2] + ref[8:], "lr": 0.01}, {"params": ref[2:8], "lr": 0.005}])
+    o_prod = FusedAdam([{"params": prod[:2] + prod[8:], "lr": 0.01}, {"params": prod[2:8], "lr": 0.005}])
+    s_ref = torch.optim.lr_scheduler.CosineAnnealingLR(o_ref, T_max=steps, eta_min=0)
+    s_prod = torch.optim.lr_scheduler.CosineAnnealingLR(o_prod, T_max=steps, eta_min=0)
+    lo, hi = -(2 ** 8 - 1) / 2 ** 9, 0.5
+    o_prod.set_clamp(prod[:2], lo, hi)
+    for it in range(steps):
+        for k, (r, q) in enumerate(zip(ref, prod)):
+            if k == 8 and it % 3 != 0:                       # a grid of another level: no gradient on most steps
+                r.grad, q.grad = None, None
+                continue
+            gr = torch.randn(*r.shape, generator=g) * (0.5 if k < 2 else 0.1)
+            r.grad, q.grad = gr.clone(), gr.to(dev)
+        o_ref.step(); s_ref.step()
+        o_prod.step(); s_prod.step()
+        with torch.no_grad():
+            for r in ref[:2]:
+                r.clamp_(lo, hi)                             # fp_quantize_clamp (fp_def.py:227-232)
+    for k, (r, q) in enumerate(zip(ref, prod)):
+        assert_rel(q.detach(), r.detach(), 2e-6, f"fused adam tensor {k}")
+    assert float(prod[0].max()) <= np.float32(hi) and float(prod[0].min()) >= np.float32(lo)
+    assert int(o_prod.state[prod[8]]["step"]) == 4 and int(o_prod.state[prod[0]]["step"]) == steps
+    sd = o_prod.state_dict()                                 # torch.optim.Adam's layout: loads into the stock optimiser
+    o_chk = torch.optim.Adam([{"params": [p.detach().clone().requires_grad_(True) for p in prod[:2] + prod[8:]], "lr": 0.01},
+                              {"params": [p.detach().clone().requires_grad_(True) for p in prod[2:8]], "lr": 0.005}])
+    o_chk.load_state_dict(sd)
+
+
 # ------------------------------------------------------------------------------------------------ full-size properties
 def test_full_size_4k_properties(dev):
     """BASELINE config 2 (3840 x 2160 image, dense G0/G1 pair): too big for the oracle end to end, so

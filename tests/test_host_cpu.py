@@ -49,21 +49,28 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_path_desc_layout_matches_the_c_header():
-    from neural_image_compression_v2_amd._lib import NicMlp, NicPathDesc
+    from neural_image_compression_v2_amd._lib import NicAdamTensor, NicMlp, NicPathDesc
     fields = [f[0] for f in NicPathDesc._fields_]
+    afields = [f[0] for f in NicAdamTensor._fields_]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(){",
             'printf("%zu\\n", sizeof(nic_path_desc));']
     prog += [f'printf("%zu\\n", offsetof(nic_path_desc, {f}));' for f in fields]
-    prog += ['printf("%zu\\n", sizeof(nic_mlp));', "return 0;}"]
+    prog += ['printf("%zu\\n", sizeof(nic_mlp));', 'printf("%zu\\n", sizeof(nic_adam_tensor));']
+    prog += [f'printf("%zu\\n", offsetof(nic_adam_tensor, {f}));' for f in afields]
+    prog += ["return 0;}"]
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
         open(src, "w").write("\n".join(prog))
         subprocess.run(["gcc", "-std=c11", src, "-o", exe], check=True)
         vals = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    nf = len(fields)
     assert vals[0] == ctypes.sizeof(NicPathDesc)
-    for f, off in zip(fields, vals[1:-1]):
+    for f, off in zip(fields, vals[1:1 + nf]):
         assert getattr(NicPathDesc, f).offset == off, f
-    assert vals[-1] == ctypes.sizeof(NicMlp)
+    assert vals[1 + nf] == ctypes.sizeof(NicMlp)
+    assert vals[2 + nf] == ctypes.sizeof(NicAdamTensor)
+    for f, off in zip(afields, vals[3 + nf:]):
+        assert getattr(NicAdamTensor, f).offset == off, f
 
 
 def test_no_cpu_path():
