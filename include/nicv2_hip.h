@@ -151,6 +151,14 @@ int nic_decoder_backward(const nic_mlp *mlp, const float *x, const float *dy, in
 int nic_fused_forward(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
                       const nic_mlp *mlp, const float *noise, float *y, void *stream);
 
+/* ---- decode straight from the stored codec (image_compression.py:307-346 after fp_load, fp_def.py:258-263):
+ *      the grids are the uint8 tensors fp_savable wrote (models.py:61-64), dequantised in-kernel exactly like load4fp
+ *      (models.py:68-71), so the result is bit-identical to nic_load4fp_u8 + nic_fused_forward at a quarter of the grid bytes.
+ *      desc->num_bits is the codec's bit depth (1..8); desc->noise_mode must be NIC_NOISE_NONE.
+ *      y: fp32 [N,3] and/or y_u8: quantize_to_bit(y) as bytes (models.py:39-40) - at least one. */
+int nic_fused_forward_u8(const nic_path_desc *desc, const uint8_t *g0_u8, const uint8_t *g1_u8, const int32_t *origins,
+                         const nic_mlp *mlp, float *y, uint8_t *y_u8, void *stream);
+
 /* ---- fused training step core: encode + noise + decoder + MSE loss + full backward.  Replaces
  *      image_compression.py:239-265 (create_decoder_input_*, rand_like noise, decoder(...), MSELoss, backward).
  *      target = [N,3].  y may be null.  loss = 1 float (the mean, desc->loss_scale * sum of squared error).

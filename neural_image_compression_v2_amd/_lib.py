@@ -71,6 +71,7 @@ SIGNATURES = {
     "nic_decoder_forward": (_I, [_M, _P, _L, _I, _I, _P, _P]),
     "nic_decoder_backward": (_I, [_M, _P, _P, _L, _I, _I, _P, _G, _P, _SZ, _P]),
     "nic_fused_forward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
+    "nic_fused_forward_u8": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_backward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _P, _P, _G, _P, _SZ, _P]),
     "nic_fused_backward_dy": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _G, _P, _SZ, _P]),
     "nic_quantize": (_I, [_P, _P, _L, _I, _P]),

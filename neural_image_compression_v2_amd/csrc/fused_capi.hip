@@ -176,6 +176,27 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
 }
 
+int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uint8_t* g1_u8, const int32_t* origins, const nic_mlp* mlp,
+                         float* y, uint8_t* y_u8, void* stream) {
+    const int layout = pick_layout(d);
+    if (layout < 0) return layout;
+    int rc = check_geometry(d);
+    if (rc) return rc;
+    if (!g0_u8 || !g1_u8 || !origins || !mlp_ok(mlp) || (!y && !y_u8)) return NIC_E_NULL;
+    if (d->noise_mode != NIC_NOISE_NONE) return NIC_E_ARG;            // decoding never adds noise (image_compression.py:307-346)
+    if (d->num_bits < 1 || d->num_bits > 8) return NIC_E_ARG;
+    const FusedInfo fi = info_of(layout);
+    FusedParams p = zero_params();
+    fill_encode(p, d, fi, reinterpret_cast<const float*>(g0_u8), reinterpret_cast<const float*>(g1_u8), origins, nullptr);
+    fill_mlp(p, mlp);
+    p.grid_u8 = 1;
+    p.dq_sub = (float)((1 << (d->num_bits - 1)) - 1);
+    p.dq_den = (float)((1 << d->num_bits) - 1);
+    p.dq_rcp = 1.0f / p.dq_den;
+    p.y = y; p.y_u8 = y_u8;
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
+}
+
 int nic_fused_forward_backward(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
                                const float* noise, const float* target, float* y, float* loss, float* g0_grad, float* g1_grad,
                                const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {

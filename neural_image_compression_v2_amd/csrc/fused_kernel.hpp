@@ -46,6 +46,9 @@ struct FusedParams {
     const float* target;   // MODE_TRAIN_MSE: [N, 3]
     const float* dy;       // MODE_TRAIN_DY:  [N, 3]
     float* y;              // [N, 3] or null
+    uint8_t* y_u8;         // [N, 3] or null: quantize_to_bit(y) as bytes (models.py:39-40)
+    float dq_sub, dq_den, dq_rcp;   // uint8 grids (decode from the stored codec): value = (u - dq_sub) / dq_den (models.py:68-71)
+    int grid_u8;
     float* partials;       // workspace, [n_waves][REC]
     int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;
@@ -203,6 +206,22 @@ __device__ __forceinline__ float g1_blend(const float* pc, const GridView& g, co
     return sum;
 }
 
+// One grid element.  GT = float: the training grids.  GT = uint8_t: the stored codec (save4fp, models.py:61-64), dequantised
+// on the fly exactly like load4fp (models.py:68-71): (u - (2^(b-1) - 1)) / (2^b - 1), correctly rounded - the numerator is an
+// exact small integer, the quotient comes from the reciprocal plus one residual correction (checked against true division for
+// every byte and every bit depth in tests/test_oracle_golden.py) - so decoding from bytes is bit-identical to fp_load + the
+// fp32 kernel.
+template <class GT>
+__device__ __forceinline__ float grid_elem(const FusedParams& p, const float* base, int64_t plane_off, uint32_t voff) {
+    if constexpr (sizeof(GT) == 1) {
+        const float n = (float)(reinterpret_cast<const uint8_t*>(base) + plane_off)[voff] - p.dq_sub;
+        const float q = mul_rn(n, p.dq_rcp);
+        return fmaf(fmaf(-q, p.dq_den, n), p.dq_rcp, q);
+    } else {
+        return (base + plane_off)[voff];
+    }
+}
+
 // corner offsets of G0 slot group e (the lane-half h fixes dx = h), per layout
 template <class L>
 __device__ __forceinline__ void g0_corner(int e, int h, int& dx, int& dy, int& dz) {
@@ -226,7 +245,7 @@ __device__ __forceinline__ void cell_offsets(const FusedParams& p, const int (&q
 }
 
 // Fills the lane's slots (see Layout<> in nic_device.hpp) for the sample at ABSOLUTE coordinates q = origin + index.
-template <class L>
+template <class L, class GT>
 __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q)[3], int h, float (&xs)[L::NSLOT], EncCtx& cx) {
     constexpr int D = L::DIM;
     const nic_path_desc& d = p.d;
@@ -251,10 +270,7 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
         g0_corner<L>(e, h, dx, dy, dz);
         const uint32_t voff = cx.off0 + (uint32_t)p.g0.at(dx, dy, dz);
 #pragma unroll
-        for (int c = 0; c < kC; ++c) {
-            const float* plane = p.g0.p + (int64_t)c * p.g0.plane;           // wave-uniform
-            xs[e * kC + c] = plane[voff];
-        }
+        for (int c = 0; c < kC; ++c) xs[e * kC + c] = grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);   // plane base: wave-uniform
     }
     __builtin_amdgcn_sched_barrier(0);
     // --- G1: channels (kC/2)*h + cc, blended with the reference's factor order
@@ -269,12 +285,11 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
         }
 #pragma unroll
         for (int cc = 0; cc < kC / 2; ++cc) {
-            const float* plane = p.g1.p + (int64_t)cc * p.g1.plane;          // wave-uniform; the lane-half part is in voff
-            float sum = 0.f;
+            float sum = 0.f;                                                  // plane base wave-uniform; the lane-half part is in voff
 #pragma unroll
             for (int q = 0; q < K1; ++q) {
                 const uint32_t b = (gf.bits >> (3 * q)) & 7u;
-                float v = plane[voff[q]];
+                float v = grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[q]);
                 v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
                 v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
                 if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
@@ -455,7 +470,7 @@ __device__ __forceinline__ void flush_grid_grads(const FusedParams& p, uint32_t 
 }
 
 // =====================================================================================================
-template <class L, int SRC, int MODE>
+template <class L, int SRC, int MODE, class GT = float>
 __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(FusedParams p) {
     using S = Lds<L>;
     constexpr bool TRAIN = MODE != MODE_INFER;
@@ -625,7 +640,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         float xs[L::NSLOT];
         EncCtx cx;
         if (SRC == SRC_ENCODE) {
-            encode_slots<L>(p, q, h, xs, cx);
+            encode_slots<L, GT>(p, q, h, xs, cx);
             add_noise<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, h, xs);
         } else {
             const float* row = p.x + n * L::CIN;
@@ -745,6 +760,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         if (p.y != nullptr && valid && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+        }
+        if (!TRAIN && p.y_u8 != nullptr && valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p.y_u8[n * 3 + c] = (uint8_t)(int)floorf(add_rn(mul_rn(yv[c], 255.0f), 0.5f));   // y in (0, 1): 0 .. 255
         }
         if (!TRAIN) continue;
 

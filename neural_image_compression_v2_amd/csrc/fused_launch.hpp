@@ -27,7 +27,9 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
         using L = Layout<METHOD>;                                                                                        \
         const dim3 g(grid), b(256);                                                                                      \
         if (src == SRC_ENCODE) {                                                                                         \
-            if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);        \
+            if (mode == MODE_INFER && p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t>), g, b, 0, s, p); \
+            else if (p.grid_u8) return NIC_E_UNSUPPORTED;                                                               \
+            else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);   \
             else if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE>), g, b, 0, s, p); \
             else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY>), g, b, 0, s, p);                        \
         } else {                                                                                                         \

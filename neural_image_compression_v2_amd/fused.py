@@ -236,6 +236,32 @@ def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torc
     return y
 
 
+def fused_forward_u8(geo: PathGeometry, g0_u8, g1_u8, coord, params, out: str = "float"):
+    """Decode from the STORED grids (the uint8 tensors ``fp_savable`` wrote, fp_def.py:250-255) without materialising fp32
+    grids: dequantisation happens in the gather, bit-identical to ``fp_load`` + :func:`fused_forward`.
+    ``out``: "float" -> fp32 [N,3]; "uint8" -> ``quantize_to_bit`` of it as bytes (models.py:39-40); "both" -> (fp32, uint8)."""
+    for name, g in (("G0", g0_u8), ("G1", g1_u8)):
+        if not isinstance(g, torch.Tensor) or g.dtype != torch.uint8:
+            raise TypeError(f"{name} must be a uint8 tensor (fp_savable output)")
+        if not g.is_cuda:
+            raise RuntimeError(f"{name} lives on {g.device}: this package only runs on a HIP device (no CPU path)")
+    g0_u8, g1_u8 = g0_u8.contiguous(), g1_u8.contiguous()
+    check_grids(geo, g0_u8, g1_u8)
+    if geo.noise_mode != NIC_NOISE_NONE:
+        raise ValueError("decoding adds no noise")
+    if out not in ("float", "uint8", "both"):
+        raise ValueError("out must be 'float', 'uint8' or 'both'")
+    params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
+    org = upload_origins(geo, coord, g0_u8.device, g0_u8, g1_u8)
+    y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0_u8.device) if out != "uint8" else None
+    yq = torch.empty(geo.n_samples, 3, dtype=torch.uint8, device=g0_u8.device) if out != "float" else None
+    d = geo.to_desc(g0_u8, g1_u8)
+    m = _mlp_struct(params)
+    _lib.check(_lib.load().nic_fused_forward_u8(ctypes.byref(d), _lib.ptr(g0_u8), _lib.ptr(g1_u8), _lib.ptr(org), ctypes.byref(m),
+                                                _lib.ptr(y), _lib.ptr(yq), _lib.stream_ptr(g0_u8.device)), "nic_fused_forward_u8")
+    return y if out == "float" else (yq if out == "uint8" else (y, yq))
+
+
 @dataclass
 class StepOutput:
     loss: torch.Tensor                       # 0-dim, the MSE mean (image_compression.py:259)

@@ -207,7 +207,9 @@ class ImageCompression:
     # ------------------------------------------------------------------ decode (image_compression.py:307-346)
     def decode_image(self, fp, arc_decoder, mip_level, pr=False, div_size=10):
         """full image at ``mip_level`` as [S, S(, S), 3] (first axis = x): one fused encode+decoder launch per tile, tiles of
-        side <= 2^div_size like the reference"""
+        side <= 2^div_size like the reference.  ``fp`` may be the fp32 grids or the STORED uint8 grids (``fp_savable`` /
+        ``load_compressed``): those are dequantised inside the gather (``nic_fused_forward_u8``), bit-identical to ``fp_load``
+        followed by the fp32 decode."""
         c = self.cfg
         D = c.FP_DIMENSION
         with torch.no_grad():
@@ -216,9 +218,11 @@ class ImageCompression:
             decode_size = c.IMAGE_SIZE // pow(2, mip_level)
             fl = self.feature_pyramid_mip_levels_dict[mip_level]
             params = arc_decoder.linear_params()
+            stored = fp[2 * fl].dtype == torch.uint8
+            run = (lambda geo, org: fused.fused_forward_u8(geo, fp[2 * fl], fp[2 * fl + 1], org, params)) if stored else \
+                  (lambda geo, org: fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], org, params))
             if div_slice == 1:
-                geo = self._geometry(fl, mip_level, decode_size, 1)
-                y = fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], [[0] * D], params)
+                y = run(self._geometry(fl, mip_level, decode_size, 1), [[0] * D])
                 return y.reshape(*([decode_size] * D), 3)
             if D != 2:
                 raise NotImplementedError("tiled decode is 2D only, like the reference (image_compression.py:329-345)")
@@ -227,9 +231,27 @@ class ImageCompression:
             geo = self._geometry(fl, mip_level, s, 1)
             for i in range(div_slice * div_slice):
                 tx, ty = i % div_slice, i // div_slice
-                y = fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], [[s * tx, s * ty]], params)
-                result[s * tx:s * (tx + 1), s * ty:s * (ty + 1), :] = y.reshape(s, s, 3)
+                result[s * tx:s * (tx + 1), s * ty:s * (ty + 1), :] = run(geo, [[s * tx, s * ty]]).reshape(s, s, 3)
             return result
+
+    # ------------------------------------------------------------------ stored form (image_compression.py:370-397)
+    def save_compressed(self, fp, fp_path: str, decoder_path: str) -> None:
+        """the two files the reference writes: ``torch.save`` of the list of uint8 grids (``fp_savable``, :376,:383) and of the
+        decoder's ``state_dict`` (:380) - readable by the reference and by :meth:`load_compressed`"""
+        from .fp_def import fp_savable
+        torch.save([g.cpu() for g in fp_savable(fp, self.cfg.FP_BITS, torch.uint8)], fp_path)
+        torch.save({k: v.cpu() for k, v in self.decoder.state_dict().items()}, decoder_path)
+
+    def load_compressed(self, fp_path: str, decoder_path: str, dequantise: bool = False):
+        """reads files written by :meth:`save_compressed` or by the reference (:391-396).  Returns the grids as stored (uint8,
+        on the device: decode them directly) or, with ``dequantise``, as fp32 like ``fp_load`` (fp_def.py:258-263)."""
+        from .fp_def import fp_load
+        self.decoder.load_state_dict(torch.load(decoder_path, map_location="cpu"))
+        self.decoder.eval()
+        stored = [g.to(self.device) for g in torch.load(fp_path, map_location="cpu")]
+        if any(g.dtype != torch.uint8 for g in stored):
+            raise NotImplementedError("only the reference's default 8-bit uint8 container is supported")
+        return fp_load(stored, self.cfg.FP_BITS, torch.float32) if dequantise else stored
 
     def psnr(self, fp, mip_level: int = 0):
         """PSNR (peak 256) of the decode against the resident image (image_compression.py:283-289)"""

@@ -559,6 +559,24 @@ def g10_trajectory(ref_models, ref_utils, ref_fp):
     save("trajectory", **out)
 
 
+def g11_stored(ref_models, ref_utils, ref_fp):
+    """The stored form the reference writes (image_compression.py:376-383): ``torch.save`` of the fp_savable uint8 list and of
+    the decoder state_dict - committed as the two tiny .pth files themselves (data, 8 KiB) - plus the reference's own decode
+    of them (decode_image on fp_load(..., float32) grids, :307-346) at 64 x 64 as the expected output."""
+    ns = driver_namespace(ref_models, ref_utils, ref_fp, IMAGE_SIZE=64, CROP_MIP_LEVEL=6)
+    torch.manual_seed(71)
+    fp, _ = ref_fp.create_pyramid(ns["FEATURE_PYRAMID_SIZE"], 12, 8, "cpu", torch.float32, True)   # [12,17,17], [12,9,9]
+    decoder = ns["ColorDecoder"]()
+    ns["feature_pyramid_mip_levels_dict"] = ref_fp.create_pyramid_mip_levels(64, ns["FEATURE_PYRAMID_SIZE"])
+    stored = ref_fp.fp_savable([g.detach() for g in fp], 8, torch.uint8)
+    os.makedirs(OUT, exist_ok=True)
+    torch.save(stored, os.path.join(OUT, "stored_feature_pyramid.pth"))
+    torch.save(decoder.state_dict(), os.path.join(OUT, "stored_decoder.pth"))
+    loaded = ref_fp.fp_load(stored, 8, torch.float32)
+    y = ns["decode_image"](loaded, decoder, 0, pr=False)                                            # [64, 64, 3]
+    save("stored_decode", y=y, y_to_bit=ref_models.quantize_to_bit(y, 8), g0_u8=stored[0], g1_u8=stored[1])
+
+
 def main():
     torch.set_num_threads(4)
     ref_models, ref_utils, ref_fp, ref_pe = load_reference_modules()
@@ -571,6 +589,7 @@ def main():
     g8b_fwdbwd_mip0(ref_models, ref_utils, ref_fp)
     g9_codec(ref_models, ref_utils)
     g10_trajectory(ref_models, ref_utils, ref_fp)
+    g11_stored(ref_models, ref_utils, ref_fp)
     assert not any("__pycache__" in d for d, _, _ in os.walk("/root/reference")), "bytecode written into reference"
 
 

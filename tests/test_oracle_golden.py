@@ -2,6 +2,7 @@
 itself (oracle/make_golden.py).  Index / encode / codec arithmetic must be bit-exact; the
 floating-point network is held to 1e-6 (different BLAS blocking orders are the only freedom)."""
 import math
+import os
 import random
 
 import numpy as np
@@ -349,3 +350,38 @@ def test_kernel_noise_statistics():
     assert not torch.equal(n, O.kernel_noise(4096, 73, 8, seed=7, offset=4))
     assert not torch.equal(n, O.kernel_noise(4096, 73, 8, seed=8, offset=3))
     assert torch.equal(n[100:200], O.kernel_noise(100, 73, 8, seed=7, offset=3, sample_base=100))
+
+
+def test_stored_decode_fixture_and_in_kernel_dequantisation_formula():
+    """(a) the oracle decodes the files the reference wrote (tests/golden/stored_*.pth: fp_savable list + decoder state_dict,
+    image_compression.py:376-383) to the reference's own decode_image output; (b) the dequantisation the uint8 decode kernel
+    uses - q = n * r, q += fma(-q, d, n) * r with n = u - (2^(b-1) - 1), d = 2^b - 1, r = fl(1/d) - is the correctly rounded
+    n / d of load4fp (models.py:68-71) for every byte and bit depth (exact rational arithmetic)."""
+    from fractions import Fraction
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stored_decode.npz"))
+    stored = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stored_feature_pyramid.pth"))
+    sd = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stored_decoder.pth"))
+    assert [tuple(t.shape) for t in stored] == [(12, 17, 17), (12, 9, 9)] and all(t.dtype == torch.uint8 for t in stored)
+    assert np.array_equal(stored[0].numpy(), g["g0_u8"]) and np.array_equal(stored[1].numpy(), g["g1_u8"])
+    mlp = O.MLPParams([sd[f"decoder.{i}.weight"] for i in (0, 2, 4)], [sd[f"decoder.{i}.bias"] for i in (0, 2, 4)])
+    fp = [O.load4fp(t, 8) for t in stored]
+    cfg = O.TrainConfig(IMAGE_SIZE=64, CROP_MIP_LEVEL=6)
+    y = O.decode_image(fp, mlp, cfg, 0)
+    assert float((y - torch.from_numpy(g["y"])).abs().max()) <= 2e-6
+    assert np.array_equal(np.rint(O.quantize_to_bit(y).numpy()), np.rint(g["y_to_bit"]))
+
+    def rn_exact(fr: Fraction):
+        a = np.float32(float(fr))                 # candidate; fix a possible double-rounding by checking its neighbours
+        best = min((a, np.nextafter(a, np.float32(np.inf)), np.nextafter(a, np.float32(-np.inf))),
+                   key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1))
+        return np.float32(best)
+
+    for b in range(1, 9):
+        d = np.float32(2 ** b - 1)
+        r = np.float32(1.0) / d
+        for u in range(256):
+            n = np.float32(u) - np.float32(2 ** (b - 1) - 1)
+            q = rn_exact(Fraction(float(n)) * Fraction(float(r)))
+            e = rn_exact(Fraction(float(n)) - Fraction(float(q)) * Fraction(float(d)))
+            q2 = rn_exact(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
+            assert q2 == n / d, (b, u)
