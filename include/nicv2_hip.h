@@ -151,6 +151,23 @@ int nic_decoder_backward(const nic_mlp *mlp, const float *x, const float *dy, in
 int nic_fused_forward(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
                       const nic_mlp *mlp, const float *noise, float *y, void *stream);
 
+/* ---- the same training step with the target read straight from a resident image instead of an [N,3] tensor (SURVEY 8f
+ *      rank 3; the sampler's slicing / reshape / stack of image_compression.py:37-47 disappears): sample i of crop k takes
+ *      image[c][origin_k + i].  `data` is the reference's dataset tensor [3, S0, S1(, S2)] (first spatial axis = first sample
+ *      axis), contiguous, fp32 - or uint8 codes with target = u / den, correctly rounded like torch's true division (den 255:
+ *      ToTensor, image_compression.py:436-440; den 256: the 3D loader, :474).  Every origin + extent must lie inside `size`. */
+typedef struct nic_target_image {
+    const void *data;
+    int32_t is_u8;
+    float den;           /* uint8 only */
+    int32_t size[3];     /* S0, S1, S2 (1 for 2D) */
+    int32_t reserved;
+} nic_target_image;
+int nic_fused_forward_backward_img(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                                   const nic_mlp *mlp, const float *noise, const nic_target_image *image, float *y, float *loss,
+                                   float *g0_grad, float *g1_grad, const nic_mlp_grads *grads, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
 /* ---- decode straight from the stored codec (image_compression.py:307-346 after fp_load, fp_def.py:258-263):
  *      the grids are the uint8 tensors fp_savable wrote (models.py:61-64), dequantised in-kernel exactly like load4fp
  *      (models.py:68-71), so the result is bit-identical to nic_load4fp_u8 + nic_fused_forward at a quarter of the grid bytes.

@@ -52,6 +52,12 @@ class NicAdamTensor(ctypes.Structure):
                 ("clamp_hi", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
+class NicTargetImage(ctypes.Structure):
+    """struct nic_target_image (include/nicv2_hip.h)."""
+    _fields_ = [("data", ctypes.c_void_p), ("is_u8", ctypes.c_int32), ("den", ctypes.c_float), ("size", ctypes.c_int32 * 3),
+                ("reserved", ctypes.c_int32)]
+
+
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _D = ctypes.POINTER(NicPathDesc)
 _M = ctypes.POINTER(NicMlp)
@@ -73,6 +79,7 @@ SIGNATURES = {
     "nic_fused_forward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_u8": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_backward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _P, _P, _G, _P, _SZ, _P]),
+    "nic_fused_forward_backward_img": (_I, [_D, _P, _P, _P, _M, _P, ctypes.POINTER(NicTargetImage), _P, _P, _P, _P, _G, _P, _SZ, _P]),
     "nic_fused_backward_dy": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _G, _P, _SZ, _P]),
     "nic_quantize": (_I, [_P, _P, _L, _I, _P]),
     "nic_quantize_to_bit": (_I, [_P, _P, _L, _I, _P]),

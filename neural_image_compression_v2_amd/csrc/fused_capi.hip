@@ -120,13 +120,19 @@ FusedParams zero_params() {
 
 int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp, const float* noise,
                 const float* target, const float* dy, float* y, float* loss, float* g0_grad, float* g1_grad, const nic_mlp_grads* grads,
-                void* workspace, size_t workspace_bytes, void* stream) {
+                void* workspace, size_t workspace_bytes, void* stream, const nic_target_image* img = nullptr) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
     int rc = check_geometry(d);
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !g0_grad || !g1_grad || !grads || !workspace) return NIC_E_NULL;
-    if ((target == nullptr) == (dy == nullptr)) return NIC_E_ARG;
+    if ((target != nullptr) + (dy != nullptr) + (img != nullptr) != 1) return NIC_E_ARG;
+    if (img) {
+        if (!img->data) return NIC_E_NULL;
+        for (int a = 0; a < d->dim; ++a)
+            if (img->size[a] < d->extent[a]) return NIC_E_SHAPE;
+        if (img->is_u8 && !(img->den > 0.f)) return NIC_E_ARG;
+    }
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
     const FusedInfo fi = info_of(layout);
     FusedParams p = zero_params();
@@ -134,14 +140,26 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     fill_mlp(p, mlp);
     p.g0_grad = g0_grad; p.g1_grad = g1_grad;
     p.target = target; p.dy = dy; p.y = y;
+    if (img) {
+        // [3, S0, S1(, S2)] contiguous: the last sample axis is the unit-stride one
+        const int64_t s2 = d->dim == 3 ? img->size[2] : 1;
+        p.timg = img->data;
+        p.timg_s[2] = d->dim == 3 ? 1 : 0;
+        p.timg_s[1] = s2;
+        p.timg_s[0] = (int64_t)img->size[1] * s2;
+        p.timg_cs = (int64_t)img->size[0] * p.timg_s[0];
+        p.timg_u8 = img->is_u8 ? 1 : 0;
+        p.timg_den = img->is_u8 ? img->den : 1.0f;
+        p.timg_rcp = 1.0f / p.timg_den;
+    }
     p.partials = (float*)workspace;
     const int grid = grid_for(p.n_tiles, 1);
     const int n_rec = grid * 4 / fi.waves_per_rec;
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    rc = launch(layout, SRC_ENCODE, target ? MODE_TRAIN_MSE : MODE_TRAIN_DY, p, grid, s);
+    rc = launch(layout, SRC_ENCODE, img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY), p, grid, s);
     if (rc) return rc;
-    return reduce(layout, p.partials, n_rec, *grads, target ? loss : nullptr, d->loss_scale, s);
+    return reduce(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
 }
 
 }  // namespace
@@ -202,6 +220,14 @@ int nic_fused_forward_backward(const nic_path_desc* d, const float* g0, const fl
                                const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
     if (!target || !loss) return NIC_E_NULL;
     return fused_train(d, g0, g1, origins, mlp, noise, target, nullptr, y, loss, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream);
+}
+
+int nic_fused_forward_backward_img(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
+                                   const float* noise, const nic_target_image* image, float* y, float* loss, float* g0_grad,
+                                   float* g1_grad, const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!image || !loss) return NIC_E_NULL;
+    return fused_train(d, g0, g1, origins, mlp, noise, nullptr, nullptr, y, loss, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream,
+                       image);
 }
 
 int nic_fused_backward_dy(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,

@@ -30,7 +30,7 @@
 namespace nic {
 
 enum { SRC_ENCODE = 0, SRC_MEMORY = 1 };
-enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2 };
+enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2, MODE_TRAIN_IMG = 3 };   // IMG: MSE against a resident image
 
 struct FusedParams {
     nic_path_desc d;
@@ -45,6 +45,12 @@ struct FusedParams {
     float* dx;             // SRC_MEMORY training: [n, cin] or null
     const float* target;   // MODE_TRAIN_MSE: [N, 3]
     const float* dy;       // MODE_TRAIN_DY:  [N, 3]
+    // MODE_TRAIN_IMG: the target of sample (crop, i) is image[c][origin + i] of a resident [3, (S2,) S1, S0]-strided image (the
+    // reference's dataset tensor, image_compression.py:37-47): no [N, 3] target tensor is ever materialised
+    const void* timg;
+    int64_t timg_cs, timg_s[3];      // element strides: channel, sample axes 0..2
+    int timg_u8;                     // 1: uint8 codes, target = u / timg_den (ToTensor: 255; the 3D loader: 256)
+    float timg_den, timg_rcp;
     float* y;              // [N, 3] or null
     uint8_t* y_u8;         // [N, 3] or null: quantize_to_bit(y) as bytes (models.py:39-40)
     float dq_sub, dq_den, dq_rcp;   // uint8 grids (decode from the stored codec): value = (u - dq_sub) / dq_den (models.py:68-71)
@@ -631,7 +637,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- the sample's target (or incoming dY): fetched now, used after the forward pass.  n is a valid sample index
         // for every lane (masked lanes are clamped), so the loads are unconditional and all in flight together
         float tgt[3] = {0.f, 0.f, 0.f};
-        if (TRAIN) {
+        if (MODE == MODE_TRAIN_IMG) {
+            int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
+            if (L::DIM == 3) off += (int64_t)q[2] * p.timg_s[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (p.timg_u8) {
+                    const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                    const float t0 = mul_rn(u, p.timg_rcp);                               // correctly rounded u / den, as in grid_elem
+                    tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
+                } else {
+                    tgt[c] = (reinterpret_cast<const float*>(p.timg) + c * p.timg_cs)[off];
+                }
+            }
+        } else if (TRAIN) {
             const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
@@ -775,7 +794,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float g;
-                if (MODE == MODE_TRAIN_MSE) {
+                if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
                     const float diff = own ? yv[c] - tgt[c] : 0.f;
                     accLoss += diff * diff;
                     g = p.grad_scale * diff;

@@ -31,6 +31,7 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
             else if (p.grid_u8) return NIC_E_UNSUPPORTED;                                                               \
             else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);   \
             else if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE>), g, b, 0, s, p); \
+            else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_IMG>), g, b, 0, s, p); \
             else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY>), g, b, 0, s, p);                        \
         } else {                                                                                                         \
             if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_MEMORY, MODE_INFER>), g, b, 0, s, p);        \

@@ -262,6 +262,39 @@ def fused_forward_u8(geo: PathGeometry, g0_u8, g1_u8, coord, params, out: str = 
     return y if out == "float" else (yq if out == "uint8" else (y, yq))
 
 
+class TargetImage:
+    """A resident image as the training target: pass it as ``target`` to :func:`fused_forward_backward` and
+    sample i of crop k is compared with ``image[:, origin_k + i]`` - the reference's ``crop.reshape(3, -1).T`` stack
+    (image_compression.py:37-47) is never built.  ``image``: the dataset tensor ``[3, S0, S1(, S2)]`` on the device, fp32, or
+    uint8 codes with ``den`` (255: ToTensor, :436-440; 256: the 3D loader, :474; value = u / den, correctly rounded)."""
+
+    def __init__(self, image: torch.Tensor, den: float = 255.0):
+        if not isinstance(image, torch.Tensor) or image.dim() not in (3, 4) or image.shape[0] != 3:
+            raise ValueError("image must be [3, S0, S1] or [3, S0, S1, S2]")
+        if not image.is_cuda:
+            raise RuntimeError(f"image lives on {image.device}: this package only runs on a HIP device (no CPU path)")
+        if image.dtype not in (torch.float32, torch.uint8):
+            raise NotImplementedError("resident images are fp32 or uint8")
+        self.image = image.contiguous()
+        self.den = float(den)
+
+    def to_struct(self, geo: "PathGeometry", coord) -> _lib.NicTargetImage:
+        if self.image.dim() != geo.dim + 1:
+            raise ValueError("image / geometry dimension mismatch")
+        if not (isinstance(coord, torch.Tensor) and coord.is_cuda):     # device origins are taken as is (no sync), like upload_origins
+            o = torch.as_tensor(coord).reshape(-1, geo.dim).to(torch.int64)
+            for a in range(geo.dim):
+                if int(o[:, a].min()) < 0 or int(o[:, a].max()) + int(geo.extent[a]) > int(self.image.shape[1 + a]):
+                    raise IndexError(f"axis {a}: crop leaves the image ({int(o[:, a].max())} + {geo.extent[a]} > {self.image.shape[1 + a]})")
+        t = _lib.NicTargetImage()
+        t.data = self.image.data_ptr()
+        t.is_u8 = 1 if self.image.dtype == torch.uint8 else 0
+        t.den = self.den
+        for a in range(3):
+            t.size[a] = int(self.image.shape[1 + a]) if a < geo.dim else 1
+        return t
+
+
 @dataclass
 class StepOutput:
     loss: torch.Tensor                       # 0-dim, the MSE mean (image_compression.py:259)
@@ -294,9 +327,13 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     check_grids(geo, g0, g1)
     params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
     org = upload_origins(geo, coord, g0.device, g0, g1)
-    target = _lib.require_cuda_f32(target, "target").reshape(-1, 3)
-    if target.shape[0] != geo.n_samples:
-        raise ValueError(f"target has {target.shape[0]} rows, geometry has {geo.n_samples} samples")
+    timg = None
+    if isinstance(target, TargetImage):
+        timg = target.to_struct(geo, coord)
+    else:
+        target = _lib.require_cuda_f32(target, "target").reshape(-1, 3)
+        if target.shape[0] != geo.n_samples:
+            raise ValueError(f"target has {target.shape[0]} rows, geometry has {geo.n_samples} samples")
     if geo.noise_mode == NIC_NOISE_TENSOR:
         noise = _lib.require_cuda_f32(noise, "noise")
         if tuple(noise.shape) != (geo.n_samples, geo.cin):
@@ -322,10 +359,17 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     gs = _grads_struct(gm)
     if events is not None:                   # (start, end) torch.cuda.Event pair recorded on the launch stream
         events[0].record(torch.cuda.current_stream(dev))
-    _lib.check(lib.nic_fused_forward_backward(
-        ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
-        _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(target), _lib.ptr(y), _lib.ptr(views[0]),
-        _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_forward_backward")
+    noise_p = _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None)
+    if timg is not None:
+        _lib.check(lib.nic_fused_forward_backward_img(
+            ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m), noise_p, ctypes.byref(timg), _lib.ptr(y),
+            _lib.ptr(views[0]), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+            "nic_fused_forward_backward_img")
+    else:
+        _lib.check(lib.nic_fused_forward_backward(
+            ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m), noise_p, _lib.ptr(target), _lib.ptr(y),
+            _lib.ptr(views[0]), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+            "nic_fused_forward_backward")
     if events is not None:
         events[1].record(torch.cuda.current_stream(dev))
     return StepOutput(views[0][0], y, gg0, gg1, gm, flat)

@@ -141,15 +141,42 @@ class ImageCompression:
             coord.append(start)
         return torch.stack(crops), torch.stack(coord), lod
 
+    def random_crop_origins(self, datasets, crop_size, num_crops, uniform_distribution, dim=2):
+        """the sampler without the crops: the SAME host RNG calls in the same order as :meth:`random_crop_dataset` (python
+        ``random`` for the LOD, ``torch.randint`` per crop), so both draw identical (origins, lod) from identical seeds; the
+        fused step then reads its targets straight from the resident image (``fused.TargetImage``)."""
+        c = self.cfg
+        if uniform_distribution:
+            lod = random.randint(0, c.MAX_MIP_LEVEL)
+        else:
+            lod = min(int(math.floor(-math.log2(random.random()) / 2)), c.MAX_MIP_LEVEL)
+        data_size = datasets[lod].shape[1]
+        re_crop = max(1, crop_size // pow(2, lod))
+        coord = [torch.randint(0, data_size - re_crop + 1, (dim,)) for _ in range(num_crops)]
+        return torch.stack(coord), lod
+
+    def set_images(self, images: Sequence[torch.Tensor], den: float = 255.0) -> None:
+        """the resident dataset, one ``[3, S(, S), S]`` tensor per LOD (image_compression.py:429-477): fp32 like the reference's,
+        or the uint8 codes they were made from (``ToTensor`` = u / 255; the 3D loader = u / 256) at a quarter of the memory"""
+        self.images = [im.to(self.device) for im in images]
+        self._targets = [fused.TargetImage(im, den) for im in self.images]
+
     # ------------------------------------------------------------------ one training iteration
     def train_step(self, fp, epoch: int, fused_step: bool = True, noise_seed: int = 7):
         """body of the loop in train_models (image_compression.py:221-269); returns the loss (device scalar)"""
         c = self.cfg
         D = c.FP_DIMENSION
-        inputs, coord, lod = self.random_crop_dataset(self.images, c.CROP_SIZE, c.NUM_CROPS, self._uniform(), dim=D)
-        fl = self.feature_pyramid_mip_levels_dict[lod]
+        resident = fused_step and len(getattr(self, "_targets", ())) == len(self.images) and len(self.images) > 0
+        if resident:
+            coord, lod = self.random_crop_origins(self.images, c.CROP_SIZE, c.NUM_CROPS, self._uniform(), dim=D)
+            fl = self.feature_pyramid_mip_levels_dict[lod]
+            resident = fp[2 * fl].requires_grad
+            target = self._targets[lod] if resident else self._crops(self.images[lod], coord, max(1, c.CROP_SIZE // pow(2, lod)))
+        else:
+            inputs, coord, lod = self.random_crop_dataset(self.images, c.CROP_SIZE, c.NUM_CROPS, self._uniform(), dim=D)
+            fl = self.feature_pyramid_mip_levels_dict[lod]
+            target = inputs.reshape(-1, 3)
         noisy = epoch < c.NUM_EPOCHS * 0.95
-        target = inputs.reshape(-1, 3)
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
@@ -178,6 +205,20 @@ class ImageCompression:
         if not isinstance(self.optimizer, FusedAdam):
             fp_quantize_clamp(fp, fl, c.FP_BITS)                                                       # :269
         return loss.detach()
+
+    def _crops(self, dataset: torch.Tensor, coord: torch.Tensor, re_crop: int) -> torch.Tensor:
+        """[num_crops * n, 3] fp32 targets of the given origins, materialised (the unfused tail after the freeze)"""
+        D = dataset.dim() - 1
+        den = self._targets[0].den if dataset.dtype == torch.uint8 else 1.0
+        rows = []
+        for start in coord:
+            sl = tuple(slice(int(start[d]), int(start[d]) + re_crop) for d in range(D))
+            rows.append(dataset[(slice(None), *sl)].reshape(3, -1).T)
+        t = torch.cat(rows)
+        if dataset.dtype != torch.uint8:
+            return t
+        lut = (torch.arange(256, dtype=torch.float32) / den).to(t.device)    # divided on the host: correctly rounded, like ToTensor
+        return lut[t.long()]
 
     def _uniform(self) -> bool:
         self._acc = getattr(self, "_acc", 0.0) + self.cfg.UNIFORM_DISTRIBUTION_RATE                    # :221-226
@@ -258,5 +299,8 @@ class ImageCompression:
         D = self.cfg.FP_DIMENSION
         rec = self.decode_image(fp, self.decoder, mip_level)
         perm = (1, 2, 0) if D == 2 else (1, 2, 3, 0)
-        ref = self.images[mip_level].permute(*perm).contiguous()
+        ref = self.images[mip_level]
+        if ref.dtype == torch.uint8:                       # resident codes (set_images): the value ToTensor / the 3D loader held
+            ref = (torch.arange(256, dtype=torch.float32) / self._targets[mip_level].den).to(ref.device)[ref.long()]
+        ref = ref.permute(*perm).contiguous()
         return calculate_psnr(quantize_to_bit(rec, self.cfg.OUTPUT_BITS), quantize_to_bit(ref, self.cfg.OUTPUT_BITS))

@@ -520,6 +520,43 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
         fused.fused_forward_u8(geo, fp32[0], fp32[1], [[0, 0]], ic.decoder.linear_params())
 
 
+def test_targets_from_the_resident_image(dev):
+    """the training step that reads its targets from the resident image (fp32 or uint8 codes) gives the
+    step with the reference's materialised crop stack (image_compression.py:37-47): same outputs bit for bit, loss and
+    gradients to fp32 rounding (a different kernel instantiation); 2D and 3D (den 256, :474), off-origin crops."""
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.image_compression import ColorDecoder
+    gen = torch.Generator().manual_seed(21)
+    cases = [(2, 1, 73, (12, 33, 33), (12, 17, 17), (128, 128), (32, 32), [[5, 64], [96, 0], [40, 40]], 255.0),
+             (3, 4, 79, (12, 9, 9, 9), (12, 5, 5, 5), (32, 32, 32), (8, 8, 8), [[0, 3, 24], [17, 9, 1]], 256.0)]
+    for dim, method, cin, s0, s1, isz, ext, orgs, den in cases:
+        g0 = (torch.rand(*s0, generator=gen) - 0.5).to(dev)
+        g1 = (torch.rand(*s1, generator=gen) - 0.5).to(dev)
+        torch.manual_seed(30 + dim)
+        dec = ColorDecoder(cin, 64).to(dev)
+        params = [p.detach() for p in dec.linear_params()]
+        img_u8 = torch.randint(0, 256, (3, *isz), generator=gen, dtype=torch.uint8)
+        img_f = (img_u8.to(torch.float32) / den).to(dev)                 # what ToTensor / the 3D loader hold (divided on the host)
+        img_u8 = img_u8.to(dev)
+        crops = []
+        for o in orgs:
+            sl = tuple(slice(o[a], o[a] + ext[a]) for a in range(dim))
+            crops.append(img_f[(slice(None), *sl)].reshape(3, -1).T)     # image_compression.py:45
+        target = torch.cat(crops)
+        geo = fused.PathGeometry(dim, method, 0.25, 0, ext, len(orgs), noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=3, noise_offset=9)
+        ref = fused.fused_forward_backward(geo, g0, g1, orgs, params, target, want_y=True)
+        for what, timg in (("fp32 image", fused.TargetImage(img_f)), ("uint8 image", fused.TargetImage(img_u8, den))):
+            out = fused.fused_forward_backward(geo, g0, g1, orgs, params, timg, want_y=True)
+            assert_exact(out.y, ref.y, what)
+            assert_rel(out.loss, ref.loss, 1e-6, what)
+            for a, b in zip(out.grad_mlp, ref.grad_mlp):
+                assert_rel(a, b, 1e-6, what)
+            assert_rel(out.grad_g0, ref.grad_g0, 1e-6, what)
+            assert_rel(out.grad_g1, ref.grad_g1, 1e-6, what)
+        with pytest.raises(IndexError):
+            fused.fused_forward_backward(geo, g0, g1, [[isz[0] - ext[0] + 1] + [0] * (dim - 1)] * len(orgs), params, fused.TargetImage(img_f))
+
+
 def test_fused_adam_matches_torch_adam_with_cosine_and_clamp(dev):
     """FusedAdam (one nic_adam_multi launch per step: two lr groups, per-parameter step counts, parameters without a gradient
     skipped, clamp folded in) against torch.optim.Adam + CosineAnnealingLR + clamp_ on the CPU (image_compression.py:266-269,
@@ -633,8 +670,9 @@ def test_kernel_noise_world_size_invariance(dev):
 
 # ------------------------------------------------------------------------------------------------ training loop
 def test_training_trajectory_and_psnr(dev):
-    """A short fit with the product's loop (fused step + torch Adam + cosine + clamp + freeze/quantise tail) against the
-    oracle's loop fed the SAME crop origins and the SAME Philox noise: loss trajectory and final PSNR (peak 256) agree
+    """A short fit with the product's loop (fused step reading its targets from the resident uint8 image + the one-launch
+    FusedAdam / clamp + cosine + freeze/quantise tail) against the oracle's loop (materialised crops, torch Adam, clamp) fed the
+    SAME crop origins and the SAME in-kernel noise: loss trajectory and final PSNR (peak 256) agree
     (north star: PSNR within 0.01 dB)."""
     import random
     from neural_image_compression_v2_amd import _lib, fused
@@ -648,7 +686,8 @@ def test_training_trajectory_and_psnr(dev):
                        for c in range(3)]) + 0.05 * (torch.rand(3, S, S, generator=gen) * 2 - 1)
     img = O.quantize(img.clamp(0, 1), 8)
     ic = ImageCompression(cfg, dev, seed=0)
-    ic.images = [img.to(dev)]
+    ic.set_images([torch.round(img * 255).to(torch.uint8)])     # resident uint8 codes: targets are read in-kernel (u / 255 = img)
+    assert torch.equal(ic.images[0].cpu().to(torch.float32) / 255, img)
     # identical initial state for the oracle
     fp_ref = [f.detach().cpu().clone() for f in ic.feature_pyramid]
     mlp_ref = O.MLPParams.from_state_dict({k: v.detach().cpu() for k, v in ic.decoder.state_dict().items()})

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_path_desc_layout_matches_the_c_header():
-    from neural_image_compression_v2_amd._lib import NicAdamTensor, NicMlp, NicPathDesc
+    from neural_image_compression_v2_amd._lib import NicAdamTensor, NicMlp, NicPathDesc, NicTargetImage
     fields = [f[0] for f in NicPathDesc._fields_]
     afields = [f[0] for f in NicAdamTensor._fields_]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(){",
@@ -57,6 +57,9 @@ def test_path_desc_layout_matches_the_c_header():
     prog += [f'printf("%zu\\n", offsetof(nic_path_desc, {f}));' for f in fields]
     prog += ['printf("%zu\\n", sizeof(nic_mlp));', 'printf("%zu\\n", sizeof(nic_adam_tensor));']
     prog += [f'printf("%zu\\n", offsetof(nic_adam_tensor, {f}));' for f in afields]
+    tfields = [f[0] for f in NicTargetImage._fields_]
+    prog += ['printf("%zu\\n", sizeof(nic_target_image));']
+    prog += [f'printf("%zu\\n", offsetof(nic_target_image, {f}));' for f in tfields]
     prog += ["return 0;}"]
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
@@ -69,8 +72,12 @@ def test_path_desc_layout_matches_the_c_header():
         assert getattr(NicPathDesc, f).offset == off, f
     assert vals[1 + nf] == ctypes.sizeof(NicMlp)
     assert vals[2 + nf] == ctypes.sizeof(NicAdamTensor)
-    for f, off in zip(afields, vals[3 + nf:]):
+    na = len(afields)
+    for f, off in zip(afields, vals[3 + nf:3 + nf + na]):
         assert getattr(NicAdamTensor, f).offset == off, f
+    assert vals[3 + nf + na] == ctypes.sizeof(NicTargetImage)
+    for f, off in zip(tfields, vals[4 + nf + na:]):
+        assert getattr(NicTargetImage, f).offset == off, f
 
 
 def test_no_cpu_path():
