@@ -1,0 +1,39 @@
+"""gpurun_out/prof_TAG (ab/profile.sh) -> profiles/TAG_{bench.json,kernel_stats.csv,pmc.csv} + profiles/traffic.json"""
+import csv, glob, json, os, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
+open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write(open(stats).read())
+out = []
+vals = {}
+for i in range(1, 6):
+    f = glob.glob(os.path.join(src, f"pmc{i}", "*", "*_counter_collection.csv"))[0]
+    rows = [r for r in csv.DictReader(open(f)) if "fused_kernel" in r["Kernel_Name"]]
+    disp = sorted({int(r["Dispatch_Id"]) for r in rows})
+    dur = {}
+    for r in rows:
+        dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    names = sorted({r["Counter_Name"] for r in rows})
+    sets = open(os.path.join(src, f"pmc{i}.set")).read().strip()
+    out.append(f"# pass {i}: rocprofv3 --pmc {sets} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   "
+               f"(fused_kernel avg {sum(dur.values()) / len(dur):.3f} ms over {len(disp)} launches)")
+    for n in names:
+        per = {}
+        for r in rows:
+            if r["Counter_Name"] == n:
+                per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        v = sum(per.values()) / len(per)
+        vals[n] = v
+        out.append(f"{n},{v:.6g}")
+open(os.path.join(dst, f"{tag}_pmc.csv"), "w").write("\n".join(out) + "\n")
+traffic = {"fused_kernel_bytes_per_launch": int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
+           "raw": {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "TCC_EA0_ATOMIC_sum": vals["TCC_EA0_ATOMIC_sum"]},
+           "note": f"per launch of fused_kernel<Layout<1>,SRC_ENCODE,MODE_TRAIN_MSE> on the 4K workload; separate --pmc passes (profiles/{tag}_pmc.csv); "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of coalesced fetch bytes; the kernel's 4-12 B/lane reads are "
+                   "outside the calibrated pattern, so this is an upper bound), WRITE_SIZE as is (exact for float atomics)."}
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(line[:300]); print("\n".join(out[:12])); print(traffic["fused_kernel_bytes_per_launch"])

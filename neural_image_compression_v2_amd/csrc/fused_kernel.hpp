@@ -1129,8 +1129,13 @@ template <class L>
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves /* records */, nic_mlp_grads g, float* loss, float loss_scale) {
     using S = Lds<L>;
     constexpr int KT = S::KT;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= S::NACC * 1024 + S::TAIL) return;
+    // a block = 32 outputs x 8 slices of the record list (a serial walk over all records per output left the launch
+    // latency-bound: 52 us for 24 MB); the slices are combined through LDS in slice order - still one fixed summation tree
+    // per grid size
+    __shared__ float red[8][32];
+    const int slice = threadIdx.x >> 5;
+    const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool live = gid < S::NACC * 1024 + S::TAIL;
     // which floats of a record feed output gid: one slot, or (partial dW1 tiles, tails) one slot per wave
     int nsrc = 1, off0 = gid, stride = 0;
     if (gid < S::NACC * 1024) {
@@ -1151,16 +1156,25 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
         nsrc = 4; off0 = S::NSLOT_REC * 1024 + (gid - S::NACC * 1024); stride = 320;
     }
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
-    for (int k = 0; k < nsrc; ++k) {
-        const float* src = partials + off0 + k * stride;
-        int w = 0;
-        for (; w + 8 <= n_waves; w += 8) {
+    const int per = (n_waves + 7) >> 3;                              // records per slice
+    const int w_lo = slice * per, w_hi = (w_lo + per < n_waves) ? w_lo + per : n_waves;
+    if (live) {
+        for (int k = 0; k < nsrc; ++k) {
+            const float* src = partials + off0 + k * stride;
+            int w = w_lo;
+            for (; w + 8 <= w_hi; w += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
+                for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
+            }
+            for (; w < w_hi; ++w) part[0] += src[(int64_t)w * S::REC];
         }
-        for (; w < n_waves; ++w) part[0] += src[(int64_t)w * S::REC];
     }
-    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    red[slice][threadIdx.x & 31] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    float acc = red[0][threadIdx.x];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
     if (gid < S::NACC * 1024) {
         const int a = gid >> 10, r = (gid >> 6) & 15, lane = gid & 63;
         const int row = ROW(r, lane >> 5), col = lane & 31;

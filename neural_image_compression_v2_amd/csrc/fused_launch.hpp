@@ -44,7 +44,7 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
     int launch_reduce<METHOD>(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
         using L = Layout<METHOD>;                                                                                        \
         const int n = Lds<L>::NACC * 1024 + Lds<L>::TAIL;                                                                          \
-        hipLaunchKernelGGL((reduce_partials_kernel<L>), dim3((n + 255) / 256), dim3(256), 0, s, partials, n_waves, g, loss, loss_scale); \
+        hipLaunchKernelGGL((reduce_partials_kernel<L>), dim3((n + 31) / 32), dim3(256), 0, s, partials, n_waves, g, loss, loss_scale); \
         return (int)hipGetLastError();                                                                                   \
     }
 
