@@ -278,6 +278,79 @@ def test_fused_forward_backward_matches_oracle(dev, case):
             assert_rel(a, b, 1e-5, "decoder grads run to run")
 
 
+def test_baseline_configs_3_to_5_at_reduced_size(dev):
+    """BASELINE.json configs beyond the bench workload, as parity cases.  (3) the 33^3 colour LUT: one crop of the whole
+    volume on ceil(33/4)+1 = 10 / 6-node grids, the reference's permuted weights and the textbook-trilinear switch.
+    (4) a video as a non-cubic 3D field (T x H x W = 12 x 20 x 36, per-axis grids), method 4, the sample batch sharded 8 ways
+    exactly like 8 ranks would (loss_scale = 1/(3 N_global), sample_base = first global sample): the shard sum equals the
+    oracle's single step.  (5) independent fits launched concurrently on separate HIP streams give what they give alone."""
+    from neural_image_compression_v2_amd import _lib, fused
+    gen = torch.Generator().manual_seed(123)
+    # ---- (3) 33^3 LUT
+    for textbook in (False, True):
+        g0 = torch.rand(12, 10, 10, 10, generator=gen) - 0.5
+        g1 = torch.rand(12, 6, 6, 6, generator=gen) - 0.5
+        mlp = O.init_mlp(127, 64, generator=gen)
+        target = torch.rand(33 ** 3, 3, generator=gen)
+        ref = O.forward_backward(g0, g1, mlp, [(0, 0, 0)], (33, 33, 33), 0.25, 0, target, None, 6, method=3, textbook_weights=textbook)
+        geo = fused.PathGeometry(3, 3, 0.25, 0, (33, 33, 33), 1, textbook_weights=textbook)
+        out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), [(0, 0, 0)], [q.to(dev) for q in mlp.tensors()], target.to(dev), want_y=True)
+        assert_rel(out.y, ref.y, 5e-6, "LUT y")
+        assert_rel(out.loss, ref.loss, 1e-5, "LUT loss")
+        assert_rel(out.grad_g0, ref.grad_g0, 1e-4, "LUT grad G0")
+        assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "LUT grad G1")
+        for a, b in zip(out.grad_mlp, ref.grad_mlp):
+            assert_rel(a, b, 1e-4, "LUT decoder grads")
+    # ---- (4) video field, 8-way sample sharding
+    ext = (12, 20, 36)                                              # x <-> T, y <-> H, z <-> W (grids [c, z, y, x])
+    g0 = torch.rand(12, 10, 6, 4, generator=gen) - 0.5              # nodes per axis: ceil(12/4)+1, ceil(20/4)+1, ceil(36/4)+1
+    g1 = torch.rand(12, 6, 4, 3, generator=gen) - 0.5
+    mlp = O.init_mlp(79, 64, generator=gen)
+    params = [q.to(dev) for q in mlp.tensors()]
+    n_glob = int(np.prod(ext))
+    target = torch.rand(n_glob, 3, generator=gen)
+    noise = O.kernel_noise(n_glob, 79, 8, seed=99, offset=5)
+    ref = O.forward_backward(g0, g1, mlp, [(0, 0, 0)], ext, 0.25, 0, target, noise, 6, method=4, use_tri_pe=False)
+    tot = None
+    xs = [0, 2, 3, 5, 6, 8, 9, 11, 12]                               # 8 uneven slabs along the first axis
+    for r in range(8):
+        x0, x1 = xs[r], xs[r + 1]
+        sub = (x1 - x0, ext[1], ext[2])
+        base = x0 * ext[1] * ext[2]
+        geo = fused.PathGeometry(3, 4, 0.25, 0, sub, 1, use_tri_pe=False, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=99, noise_offset=5,
+                                 sample_base=base, loss_scale=1.0 / (3.0 * n_glob))
+        o = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), [(x0, 0, 0)], params, target[base:base + int(np.prod(sub))].to(dev))
+        tot = o.flat.clone() if tot is None else tot + o.flat      # what the all-reduce(SUM) of the flat bucket produces
+    offs, sizes, _ = fused.grad_bucket_layout(fused.PathGeometry(3, 4, 0.25, 0, ext, 1, use_tri_pe=False), g0, g1)
+    pieces = [tot[o_:o_ + s_] for o_, s_ in zip(offs, sizes)]
+    assert_rel(pieces[0][0], ref.loss, 1e-5, "sharded loss")
+    for k, b in enumerate(ref.grad_mlp):
+        assert_rel(pieces[1 + k].view(b.shape), b, 1e-4, f"sharded decoder grad {k}")
+    assert_rel(pieces[7].view(g0.shape), ref.grad_g0, 1e-4, "sharded grad G0")
+    assert_rel(pieces[8].view(g1.shape), ref.grad_g1, 1e-4, "sharded grad G1")
+    # ---- (5) concurrent independent fits, one stream each
+    fits = []
+    for k in range(4):
+        fp, _ = _pyramid(2, 32, 12, seed=40 + k)
+        mlp = O.init_mlp(73, 64, generator=gen)
+        fits.append((fp[0].to(dev), fp[1].to(dev), [q.to(dev) for q in mlp.tensors()], torch.rand(2 * 96 * 80, 3, generator=gen).to(dev)))
+    geo = fused.PathGeometry(2, 1, 0.25, 0, (96, 80), 2, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=1, noise_offset=2)
+    orgs = [(3, 9), (30, 40)]
+    alone = [fused.fused_forward_backward(geo, a, b, orgs, prm, tg) for a, b, prm, tg in fits]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in fits]
+    together = []
+    for st, (a, b, prm, tg) in zip(streams, fits):
+        with torch.cuda.stream(st):
+            together.append(fused.fused_forward_backward(geo, a, b, orgs, prm, tg))
+    torch.cuda.synchronize()
+    for one, two in zip(alone, together):
+        assert_exact(one.loss, two.loss, "concurrent fit: loss")
+        for a, b in zip(one.grad_mlp, two.grad_mlp):
+            assert_exact(a, b, "concurrent fit: decoder grads")
+        assert_rel(one.grad_g0, two.grad_g0, 1e-6, "concurrent fit: grid grads")
+
+
 def test_fused_autograd_function(dev):
     """FusedGridMLP: arbitrary downstream loss, gradients through the recompute-backward kernel"""
     from neural_image_compression_v2_amd import fused
