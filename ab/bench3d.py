@@ -12,7 +12,7 @@ for method, cin in ((3, 127), (4, 79)):
     dec = ColorDecoder(cin, 64).to(dev)
     params = [p.detach() for p in dec.linear_params()]
     target = torch.rand(S ** 3, 3, device=dev)
-    org = torch.zeros(1, 3, dtype=torch.int32, device=dev)
+    org = [[0, 0, 0]]                                        # host origins: the wrapper sees they are cell-aligned
     def step(i):
         geo = fused.PathGeometry(dim=3, method=method, step_number=0.25, mip_level=0, extent=(S, S, S), num_crops=1,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i)

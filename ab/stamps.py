@@ -4,16 +4,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from neural_image_compression_v2_amd import _lib, fused, fp_def
 from neural_image_compression_v2_amd.image_compression import ColorDecoder
-H, W = 2160, 3840
+METHOD = int(os.environ.get("METHOD", "1"))            # 1: the 4K 2D workload; 3 / 4: a 128^3 volume
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-fp, _ = fp_def.create_pyramid((H // 4, W // 4), 12, 8, dev, torch.float32, True)
-dec = ColorDecoder(73, 64).to(dev)
+if METHOD == 1:
+    H, W = 2160, 3840
+    NS = H * W
+    fp, _ = fp_def.create_pyramid((H // 4, W // 4), 12, 8, dev, torch.float32, True)
+    dec = ColorDecoder(73, 64).to(dev)
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
+                             noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1)
+    org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+else:
+    S = 128
+    NS = S ** 3
+    fp, _ = fp_def.create_pyramid_3d(S // 4, 12, 8, dev, torch.float32, True)
+    dec = ColorDecoder(127 if METHOD == 3 else 79, 64).to(dev)
+    geo = fused.PathGeometry(dim=3, method=METHOD, step_number=0.25, mip_level=0, extent=(S, S, S), num_crops=1,
+                             noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1)
+    org = torch.zeros(1, 3, dtype=torch.int32, device=dev)
 params = [p.detach() for p in dec.linear_params()]
-target = torch.rand(H * W, 3, device=dev)
-geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
-                         noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1)
-org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+target = torch.rand(NS, 3, device=dev)
 for _ in range(3):
     out = fused.fused_forward_backward(geo, fp[0].detach(), fp[1].detach(), org, params, target)
 torch.cuda.synchronize()
@@ -25,6 +36,6 @@ names = ["0 encode+noise", "1 X^T store, L1, L2, GELUs", "2 L3, dZ3, dW3 pass, d
          "12 macro-tile setup", "13 grid flush"]
 tot = st[:, :14].sum(1)
 print(f"waves {st.shape[0]}, total cycles/wave median {np.median(tot):.3e} (min {tot.min():.3e}, max {tot.max():.3e})")
-rounds = H * W / 32 / 1024
+rounds = NS / 32 / 1024
 for i, n in enumerate(names):
     print(f"{n:34s} {100 * np.median(st[:, i] / tot):6.2f} %   {np.median(st[:, i]) / rounds:9.0f} cycles/round")

@@ -119,7 +119,8 @@ def main():
     def step(i, events=None):
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
-                                 sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global))
+                                 sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global),
+                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED)  # origin (0, 0)
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
         all_reduce_flat(out.flat)                                     # RCCL sum of [loss | decoder grads | grid grads]
         cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))  # CosineAnnealingLR(T_max), eta_min = 0

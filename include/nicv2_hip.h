@@ -81,8 +81,12 @@ typedef struct nic_path_desc {
     uint64_t noise_offset;  /* e.g. the training step */
     int64_t sample_base;     /* global id of this launch's sample 0 (data-parallel shards: keeps the noise world-size invariant) */
     float loss_scale;        /* 1 / (3 * N_global): the MSELoss mean (image_compression.py:259) */
-    int32_t reserved;
+    int32_t flags;           /* NIC_FLAG_* (0 is always valid) */
 } nic_path_desc;
+/* Every crop origin is a multiple of the cell size 1 / step_number (1 when step_number >= 1), e.g. whole-image passes from
+ * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1
+ * (origins live on the device, the library cannot look). Setting it for unaligned origins drops samples. */
+#define NIC_FLAG_ORIGINS_ALIGNED 1
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */
 typedef struct nic_mlp {

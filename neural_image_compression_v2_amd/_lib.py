@@ -19,6 +19,7 @@ NIC_ABI_VERSION = 1
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
+NIC_FLAG_ORIGINS_ALIGNED = 1
 
 
 class NicPathDesc(ctypes.Structure):
@@ -30,7 +31,7 @@ class NicPathDesc(ctypes.Structure):
         ("num_crops", ctypes.c_int32), ("extent", ctypes.c_int32 * 3), ("g0_nodes", ctypes.c_int32 * 3),
         ("g1_nodes", ctypes.c_int32 * 3), ("pe_div", ctypes.c_float * 8), ("noise_mode", ctypes.c_int32),
         ("num_bits", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noise_offset", ctypes.c_uint64),
-        ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("flags", ctypes.c_int32),
     ]
 
 

@@ -85,13 +85,15 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * ez;
     p.n_total = p.n_per_crop * d->num_crops;
     // macro-tiles of fi.tx x fi.ty x fi.tz CELL BLOCKS; a cell block = m samples per axis, m = 1 / step_number (1 when the step
-    // is >= 1).  The crop origin is not known on the host, so the block count per axis is the unaligned upper bound; blocks
-    // (lanes) that fall outside the crop are masked in the kernel.
+    // is >= 1).  The crop origin is not known on the host, so the block count per axis is the unaligned upper bound unless the
+    // caller vouches for cell-aligned origins (NIC_FLAG_ORIGINS_ALIGNED); blocks (lanes) that fall outside the crop are masked
+    // in the kernel.
     p.lm = d->log2_step < 0 ? -d->log2_step : 0;
     const int m = 1 << p.lm;
     p.niter = 1;
     for (int a = 0; a < d->dim; ++a) p.niter *= m;
-    auto blocks = [&](int extent) { return (extent + m - 1) / m + (m > 1 ? 1 : 0); };
+    const bool aligned = (d->flags & NIC_FLAG_ORIGINS_ALIGNED) != 0;
+    auto blocks = [&](int extent) { return (extent + m - 1) / m + ((m > 1 && !aligned) ? 1 : 0); };
     const int tx = (blocks(d->extent[0]) + fi.tx - 1) / fi.tx, ty = (blocks(d->extent[1]) + fi.ty - 1) / fi.ty,
               tz = d->dim == 3 ? (blocks(ez) + fi.tz - 1) / fi.tz : 1;
     p.tiles_y = ty; p.tiles_z = tz;

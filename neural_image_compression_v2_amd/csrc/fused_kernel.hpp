@@ -14,7 +14,7 @@
 //     layer's MFMA wants (k-step = register index): the three forward layers and the two backward
 //     dA products chain through registers with no LDS traffic.  Only the weight-gradient products,
 //     which contract over the sample index, go through a transposed wave-private LDS image.
-//   * lanes map to grid CELLS, not to consecutive samples: a wave owns a 4 x 8 (2D) / 2 x 4 x 4 (3D) block of G0 cells and
+//   * lanes map to grid CELLS, not to consecutive samples: a wave owns a 16 x 2 (x 1 in 3D) block of G0 cells, lanes x-fastest, and
 //     walks the m^D samples inside a cell (m = 1/step_number: 16 rounds at mip 0) one per round.  All samples of a
 //     lane share their G0 corners and their G1 cell, so the input gradient - which leaves the last backward product in
 //     the registers of the lane that knows the slot's grid address - is summed in registers over the rounds and
@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
-        if (SRC == SRC_ENCODE && TRAIN && !(p.d.reserved & 1)) {
+        if (SRC == SRC_ENCODE && TRAIN) {
             combine_g1_lanes<L>(gacc, blk_off1, blk, lane);
             flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
         }

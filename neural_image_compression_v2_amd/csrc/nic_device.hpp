@@ -282,7 +282,7 @@ struct Layout<3> {
     static constexpr int PE = NIC_PE_TRIANGULAR;        // fp_def.py:169
     static constexpr int NSLOT = 64;   // KPAD = 128
     static constexpr int NGRID = 54;   // 48 G0 (4 corners) + 6 G1
-    static constexpr int TX = 2, TY = 4, TZ = 4;
+    static constexpr int TX = 16, TY = 2, TZ = 1;   // x-fastest like 2D (the 2 x 4 x 4 block touched 16 grid rows per gather: -10 %)
     __host__ __device__ static constexpr int slot_channel(int s, int h) {
         if (s < 48) return 48 * h + s;                  // G0 corner 4h + s/12
         if (s < 54) return 96 + 6 * h + (s - 48);
@@ -297,7 +297,7 @@ struct Layout<4> {
     static constexpr int PE = NIC_PE_SINUSOIDAL;        // fp_def.py:208
     static constexpr int NSLOT = 44;   // 16 + 16 + 12 -> KPAD = 88
     static constexpr int NGRID = 30;
-    static constexpr int TX = 2, TY = 4, TZ = 4;
+    static constexpr int TX = 16, TY = 2, TZ = 1;   // x-fastest like 2D (the 2 x 4 x 4 block touched 16 grid rows per gather: -10 %)
     __host__ __device__ static constexpr int slot_channel(int s, int h) {
         if (s < 24) return 24 * h + s;                  // G0 corner 2h + s/12
         if (s < 30) return 48 + 6 * h + (s - 24);

@@ -6,6 +6,7 @@ libnicv2_hip.so.  Reference citations are relative to /root/reference/Projects.
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 import math
 import os
 from dataclasses import dataclass, field, replace
@@ -63,6 +64,7 @@ class PathGeometry:
     noise_offset: int = 0
     sample_base: int = 0
     loss_scale: Optional[float] = None   # default 1 / (3 N)
+    flags: int = 0                       # NIC_FLAG_* the caller vouches for (the wrappers add ORIGINS_ALIGNED when they can see it)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -92,7 +94,7 @@ class PathGeometry:
             return NIC_G1_UNWEIGHTED                                   # Q6
         return NIC_G1_TEXTBOOK if self.textbook_weights else NIC_G1_REFERENCE
 
-    def to_desc(self, g0: torch.Tensor, g1: torch.Tensor) -> _lib.NicPathDesc:
+    def to_desc(self, g0: torch.Tensor, g1: torch.Tensor, aligned: bool = False) -> _lib.NicPathDesc:
         d = _lib.NicPathDesc()
         d.dim, d.method = self.dim, self.method
         d.channels, d.pe_channels, d.hidden = self.channels, self.pe_channels, self.hidden
@@ -115,7 +117,7 @@ class PathGeometry:
         d.noise_offset = int(self.noise_offset) & 0xFFFFFFFFFFFFFFFF
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
-        d.reserved = int(os.environ.get("NIC_DEBUG_FLAGS", "0"))     # profiling experiments only (bit 0: skip the grid-gradient scatter)
+        d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
         return d
 
 
@@ -153,6 +155,15 @@ def upload_origins(geo: PathGeometry, coord, device, g0=None, g1=None) -> torch.
     if g0 is not None:
         check_origins(geo, host, g0, g1)
     return host.to(torch.int32).to(device, non_blocking=True)
+
+
+def origins_aligned(geo: PathGeometry, coord) -> bool:
+    """True when host-visible origins are all multiples of the cell size 1 / step_number (whole-image passes, decode tiles): the
+    launch then needs no extra cell block per axis (NIC_FLAG_ORIGINS_ALIGNED).  Device-resident origins are not inspected."""
+    if isinstance(coord, torch.Tensor) and coord.is_cuda:
+        return False
+    cell = int(round(1.0 / geo.step_number)) if geo.step_number < 1 else 1
+    return bool((torch.as_tensor(coord).reshape(-1, geo.dim).to(torch.int64) % cell == 0).all())
 
 
 def _mlp_struct(params: Sequence[torch.Tensor]) -> _lib.NicMlp:
@@ -228,7 +239,7 @@ def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torc
         if tuple(noise.shape) != (geo.n_samples, geo.cin):
             raise ValueError("noise must be [N, Cin]")
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0.device)
-    d = geo.to_desc(g0, g1)
+    d = geo.to_desc(g0, g1, origins_aligned(geo, coord))
     m = _mlp_struct(params)
     _lib.check(_lib.load().nic_fused_forward(ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
                                              _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(y),
@@ -255,7 +266,7 @@ def fused_forward_u8(geo: PathGeometry, g0_u8, g1_u8, coord, params, out: str = 
     org = upload_origins(geo, coord, g0_u8.device, g0_u8, g1_u8)
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0_u8.device) if out != "uint8" else None
     yq = torch.empty(geo.n_samples, 3, dtype=torch.uint8, device=g0_u8.device) if out != "float" else None
-    d = geo.to_desc(g0_u8, g1_u8)
+    d = geo.to_desc(g0_u8, g1_u8, origins_aligned(geo, coord))
     m = _mlp_struct(params)
     _lib.check(_lib.load().nic_fused_forward_u8(ctypes.byref(d), _lib.ptr(g0_u8), _lib.ptr(g1_u8), _lib.ptr(org), ctypes.byref(m),
                                                 _lib.ptr(y), _lib.ptr(yq), _lib.stream_ptr(g0_u8.device)), "nic_fused_forward_u8")
@@ -351,7 +362,7 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     gm = [views[1 + i].view(shapes[i]) for i in range(6)]
     gg0, gg1 = views[7].view(g0.shape), views[8].view(g1.shape)
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=dev) if want_y else None
-    d = geo.to_desc(g0, g1)
+    d = geo.to_desc(g0, g1, origins_aligned(geo, coord))
     lib = _lib.load()
     ws_bytes = int(lib.nic_workspace_bytes(ctypes.byref(d)))
     ws = _lib.workspace(dev, ws_bytes)
@@ -423,6 +434,8 @@ def fused_grid_mlp(geo: PathGeometry, g0, g1, coord, params, noise: Optional[tor
     org = upload_origins(geo, coord, g0.device, g0, g1)
     if geo.noise_mode == NIC_NOISE_TENSOR:
         noise = _lib.require_cuda_f32(noise, "noise")
+    if origins_aligned(geo, coord):
+        geo = dataclasses.replace(geo, flags=geo.flags | _lib.NIC_FLAG_ORIGINS_ALIGNED)
     return FusedGridMLP.apply(g0, g1, *params, geo, org, noise)
 
 
