@@ -719,6 +719,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // ---------- layer 2
         f32x16 a2[2], d2[2];
+        float part3[3] = {0.f, 0.f, 0.f};
         {
             f32x16 z[2];
 #pragma unroll
@@ -740,10 +741,16 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 for (int j = 0; j < 4; ++j) z[to] = mfma32(aq[st & 1][j], a1[t][4 * r4 + j], z[to]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // layer 3 rides along: only 3 outputs - a 32-row MFMA tile would be 90 % padding, so each lane dots its 32 hidden
+            // values with the matching W3 columns (broadcast LDS reads, issued before the group's GELU so their latency runs
+            // under its arithmetic) and the two lane halves are added
 #pragma unroll
             for (int to = 0; to < 2; ++to)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 w3q[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) w3q[c] = ld4(&w3_row[c * LD2 + 32 * to + 8 * r4]);
                     const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
                     f32x4_t aq4, dq4;
                     gelu_and_grad4(zq, aq4, dq4);
@@ -751,31 +758,16 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     for (int j = 0; j < 4; ++j) {
                         a2[to][4 * r4 + j] = aq4[j];
                         d2[to][4 * r4 + j] = TRAIN ? dq4[j] : 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) part3[c] = fmaf(w3q[c][j], aq4[j], part3[c]);
                     }
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(1);    // X^T store, layers 1 + 2 (MFMA) and their GELUs
-        // ---------- layer 3: only 3 outputs - a 32-row MFMA tile would be 90 % padding, so each lane dots its
-        // 32 hidden values with the matching W3 columns (broadcast LDS reads) and the two halves are added
+        STAMP(1);    // X^T store, layers 1 + 2 (MFMA), their GELUs, layer 3's dot products
         float yv[3];
-        {
-            float part[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int col = 32 * t + 8 * r4;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const f32x4 w = ld4(&w3_row[c * LD2 + col]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) part[c] = fmaf(w[j], a2[t][4 * r4 + j], part[c]);
-                    }
-                }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(part[c] + __shfl_xor(part[c], 32) + B3s[c]);
-        }
+        for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(part3[c] + __shfl_xor(part3[c], 32) + B3s[c]);
         if (p.y != nullptr && valid && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
