@@ -26,6 +26,9 @@
 //     order by reduce_partials_kernel (bit-stable decoder gradients and loss).
 #pragma once
 #include "nic_device.hpp"
+#ifndef NIC_HOIST_TRAIN
+#define NIC_HOIST_TRAIN 0   // bit 0: G0, bit 1: G1 raw values gathered once per macro-tile in the training kernels
+#endif
 
 namespace nic {
 
@@ -251,8 +254,42 @@ __device__ __forceinline__ void cell_offsets(const FusedParams& p, const int (&q
 }
 
 // Fills the lane's slots (see Layout<> in nic_device.hpp) for the sample at ABSOLUTE coordinates q = origin + index.
-template <class L, class GT>
-__device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q)[3], int h, float (&xs)[L::NSLOT], EncCtx& cx) {
+// raw grid values of one cell: every sample of a lane's macro-tile lies in the same G0 cell and the same G1 cell, so they can be
+// gathered once per macro-tile instead of once per round (where the register budget allows: NIC_HOIST_*)
+template <class L>
+struct CellRaw {
+    static constexpr int NG0 = L::K0 / 2 * kC;
+    static constexpr int K1 = L::DIM == 2 ? 4 : 8;
+    float g0[NG0];              // [corner e of this half][channel]
+    float g1[K1 * (kC / 2)];    // [corner q][channel of this half]
+};
+template <class L, class GT, bool HG0, bool HG1>
+__device__ __forceinline__ void gather_cell(const FusedParams& p, uint32_t off0, uint32_t off1, int h, CellRaw<L>& raw) {
+    constexpr int D = L::DIM;
+    if (HG0) {
+#pragma unroll
+        for (int e = 0; e < CellRaw<L>::NG0 / kC; ++e) {
+            int dx, dy, dz;
+            g0_corner<L>(e, h, dx, dy, dz);
+            const uint32_t voff = off0 + (uint32_t)p.g0.at(dx, dy, dz);
+#pragma unroll
+            for (int c = 0; c < kC; ++c) raw.g0[e * kC + c] = grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);
+        }
+    }
+    if (HG1) {
+#pragma unroll
+        for (int q = 0; q < CellRaw<L>::K1; ++q) {
+            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+            const uint32_t voff = off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(kC / 2 * h) * (uint32_t)p.g1.plane;
+#pragma unroll
+            for (int cc = 0; cc < kC / 2; ++cc) raw.g1[q * (kC / 2) + cc] = grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff);
+        }
+    }
+}
+
+template <class L, class GT, bool HG0 = false, bool HG1 = false>
+__device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q)[3], int h, float (&xs)[L::NSLOT], EncCtx& cx,
+                                             const CellRaw<L>* raw = nullptr) {
     constexpr int D = L::DIM;
     const nic_path_desc& d = p.d;
     const int e = d.log2_step;
@@ -276,7 +313,8 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
         g0_corner<L>(e, h, dx, dy, dz);
         const uint32_t voff = cx.off0 + (uint32_t)p.g0.at(dx, dy, dz);
 #pragma unroll
-        for (int c = 0; c < kC; ++c) xs[e * kC + c] = grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);   // plane base: wave-uniform
+        for (int c = 0; c < kC; ++c)
+            xs[e * kC + c] = HG0 ? raw->g0[e * kC + c] : grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);   // plane base: wave-uniform
     }
     __builtin_amdgcn_sched_barrier(0);
     // --- G1: channels (kC/2)*h + cc, blended with the reference's factor order
@@ -295,7 +333,7 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
 #pragma unroll
             for (int q = 0; q < K1; ++q) {
                 const uint32_t b = (gf.bits >> (3 * q)) & 7u;
-                float v = grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[q]);
+                float v = HG1 ? raw->g1[q * (kC / 2) + cc] : grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[q]);
                 v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
                 v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
                 if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
@@ -582,10 +620,15 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         GridAcc<L> gacc;
         uint32_t blk_off0 = 0, blk_off1 = 0;
-        if (SRC == SRC_ENCODE && TRAIN) {
-            gacc.clear();
+        // which raw grid values are gathered once per macro-tile: inference has the registers for both grids
+        constexpr bool HG0 = SRC == SRC_ENCODE && (TRAIN ? (NIC_HOIST_TRAIN & 1) != 0 : true);
+        constexpr bool HG1 = SRC == SRC_ENCODE && (TRAIN ? (NIC_HOIST_TRAIN & 2) != 0 : true);
+        CellRaw<L> raw;
+        if (SRC == SRC_ENCODE && (TRAIN || HG0 || HG1)) {
             const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};
             cell_offsets<L>(p, qb, blk_off0, blk_off1);
+            if (TRAIN) gacc.clear();
+            gather_cell<L, GT, HG0, HG1>(p, blk_off0, blk_off1, h, raw);
         }
 
         STAMP(12);   // macro-tile setup
@@ -659,7 +702,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         float xs[L::NSLOT];
         EncCtx cx;
         if (SRC == SRC_ENCODE) {
-            encode_slots<L, GT>(p, q, h, xs, cx);
+            encode_slots<L, GT, HG0, HG1>(p, q, h, xs, cx, &raw);
             add_noise<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, h, xs);
         } else {
             const float* row = p.x + n * L::CIN;
@@ -807,14 +850,23 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) sb_st[(32 * t + ROWC(r)) * LDT] = a2[t][r];
         wave_lds_fence();
+        {
+            f32x4 avq[2], zvq[2][3];                                       // operands of group g + 1 are in flight during group g
+            avq[0] = ld4(&sb_lane[0]);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 av = ld4(&sb_lane[4 * g]);
+            for (int c = 0; c < 3; ++c) zvq[0][c] = ld4(&sa_bc[c * LDT]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const f32x4 zv = ld4(&sa_bc[c * LDT + 4 * g]);
+            for (int g = 0; g < 8; ++g) {
+                if (g + 1 < 8) {
+                    avq[(g + 1) & 1] = ld4(&sb_lane[4 * (g + 1)]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accW3[c] = fmaf(zv[j], av[j], accW3[c]);
+                    for (int c = 0; c < 3; ++c) zvq[(g + 1) & 1][c] = ld4(&sa_bc[c * LDT + 4 * (g + 1)]);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accW3[c] = fmaf(zvq[g & 1][c][j], avq[g & 1][j], accW3[c]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -845,10 +897,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 sb_st[(32 * t + ROWC(r)) * LDT] = a1[t][r];
             }
         wave_lds_fence();
+        {                                                              // db2[o = lane] += sum_s dZ2[o][s]   (own samples)
+            f32x4 zq8[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {                                  // db2[o = lane] += sum_s dZ2[o][s]   (own samples)
-            const f32x4 zv = ld4(&sa_lane[4 * g]);
-            accB2 += (zv[0] + zv[1]) + (zv[2] + zv[3]);
+            for (int g = 0; g < 8; ++g) zq8[g] = ld4(&sa_lane[4 * g]);     // all eight reads in flight, then the sums
+#pragma unroll
+            for (int g = 0; g < 8; ++g) accB2 += (zq8[g][0] + zq8[g][1]) + (zq8[g][2] + zq8[g][3]);
         }
         STAMP(3);    // dZ2^T / A1^T stores, db2 row pass
         wg_lds_barrier();
