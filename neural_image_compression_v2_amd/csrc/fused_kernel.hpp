@@ -305,6 +305,24 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
     cx.off1 = (uint32_t)p.g1.at(x1, y1, z1);
     cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = az.k1;
     constexpr int NG0 = L::K0 / 2 * kC;             // G0 slots per half
+    constexpr int K1 = D == 2 ? 4 : 8;
+    // Order: issue the G1 gathers, issue the G0 gathers, compute the slots that need no memory (PE, LOD, constants), THEN blend
+    // G1 - the blend is the first consumer of a gather, everything before it runs under the loads' latency.
+    // --- G1 corner values: channels (kC/2)*h + cc.  Plane base wave-uniform; the lane-half part is in voff
+    float g1v[K1 * (kC / 2)];
+    {
+        uint32_t voff[K1];
+#pragma unroll
+        for (int q = 0; q < K1; ++q) {
+            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
+            voff[q] = cx.off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(kC / 2 * h) * (uint32_t)p.g1.plane;
+        }
+#pragma unroll
+        for (int cc = 0; cc < kC / 2; ++cc)
+#pragma unroll
+            for (int q = 0; q < K1; ++q)
+                g1v[q * (kC / 2) + cc] = HG1 ? raw->g1[q * (kC / 2) + cc] : grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[q]);
+    }
     // --- G0 raw corners.  Address = (uniform channel-plane base in SGPRs) + (one 32-bit lane offset per corner): the 12
     // channel loads of a corner share ONE offset register (96 address registers otherwise)
 #pragma unroll
@@ -317,33 +335,7 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
             xs[e * kC + c] = HG0 ? raw->g0[e * kC + c] : grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);   // plane base: wave-uniform
     }
     __builtin_amdgcn_sched_barrier(0);
-    // --- G1: channels (kC/2)*h + cc, blended with the reference's factor order
-    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
-    {
-        constexpr int K1 = D == 2 ? 4 : 8;
-        uint32_t voff[K1];
-#pragma unroll
-        for (int q = 0; q < K1; ++q) {
-            const int dx = D == 2 ? (q >> 1) : ((q >> 2) & 1), dy = D == 2 ? (q & 1) : ((q >> 1) & 1), dz = D == 2 ? 0 : (q & 1);
-            voff[q] = cx.off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(kC / 2 * h) * (uint32_t)p.g1.plane;
-        }
-#pragma unroll
-        for (int cc = 0; cc < kC / 2; ++cc) {
-            float sum = 0.f;                                                  // plane base wave-uniform; the lane-half part is in voff
-#pragma unroll
-            for (int q = 0; q < K1; ++q) {
-                const uint32_t b = (gf.bits >> (3 * q)) & 7u;
-                float v = HG1 ? raw->g1[q * (kC / 2) + cc] : grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[q]);
-                v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
-                v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
-                if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
-                sum = q == 0 ? v : add_rn(sum, v);
-            }
-            xs[NG0 + cc] = sum;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // --- remaining slots: PE rows, LOD, the constant one, zero padding.  The channel of a slot is affine
+    // --- slots without memory: PE rows, LOD, the constant one, zero padding.  The channel of a slot is affine
     // in h, so its kind is known at compile time per half; only PE row / axis are lane-half dependent.
     float pdiv[kP / 2];
 #pragma unroll
@@ -374,6 +366,69 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
         }
         xs[s] = h ? v1 : v0;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- G1 blend with the reference's factor order
+    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+#pragma unroll
+    for (int cc = 0; cc < kC / 2; ++cc) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < K1; ++q) {
+            const uint32_t b = (gf.bits >> (3 * q)) & 7u;
+            float v = g1v[q * (kC / 2) + cc];
+            v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+            v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+            if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
+            sum = q == 0 ? v : add_rn(sum, v);
+        }
+        xs[NG0 + cc] = sum;
+    }
+}
+
+// The in-kernel generator in two steps: the blocks, then their application to the slots.  (Running the generator between issuing
+// the round's gathers and consuming them was tried: the 64 extra live values spill.)
+template <class L>
+struct NoiseWords {
+    static constexpr int NG0 = L::K0 / 2 * kC;              // G0 slots of a half = one channel group (see noise_block)
+    static constexpr int GB = (NG0 + 15) / 16;              // blocks per G0 group
+    static constexpr int RB0 = 2 * GB;                      // first block of the non-G0 channels
+    static constexpr int NREST = L::CIN - L::K0 * kC;
+    static constexpr int NRB = (NREST + 15) / 16;
+    U4 g[GB];
+    uint32_t rw[NRB][4];
+};
+template <class L>
+__device__ __forceinline__ void noise_words(const NoiseSrc& ns, uint64_t sample_global, int h, NoiseWords<L>& nw) {
+    using N = NoiseWords<L>;
+#pragma unroll
+    for (int j = 0; j < N::GB; ++j) nw.g[j] = noise_block(ns, sample_global, N::GB * h + j);
+#pragma unroll
+    for (int j = 0; j < N::NRB; ++j) {
+        const U4 b = noise_block(ns, sample_global, N::RB0 + j);
+        nw.rw[j][0] = b.x; nw.rw[j][1] = b.y; nw.rw[j][2] = b.z; nw.rw[j][3] = b.w;
+    }
+}
+template <class L>
+__device__ __forceinline__ void apply_noise(const NoiseSrc& ns, const NoiseWords<L>& nw, int h, float (&xs)[L::NSLOT]) {
+    using N = NoiseWords<L>;
+#pragma unroll
+    for (int j = 0; j < N::GB; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (16 * j + t < N::NG0) xs[16 * j + t] += noise_from_block(ns, nw.g[j], t);
+    // The remaining slots' channels depend on the lane-half, but for EACH half (block, word, byte) of a slot are
+    // compile-time constants: pick both candidates with constant indices and select by h - one v_cndmask per slot, no
+    // branches (a runtime channel index compiles to a divergent branch per slot and block: ~6K cycles per round).
+#pragma unroll
+    for (int s = N::NG0; s < L::NSLOT; ++s) {
+        const int ch0 = L::slot_channel(s, 0), ch1 = L::slot_channel(s, 1);
+        if (ch0 < 0 && ch1 < 0) continue;
+        const int i0 = ch0 - L::K0 * kC, i1 = ch1 - L::K0 * kC;       // index among the non-G0 channels
+        float n0 = 0.f, n1 = 0.f;
+        if (ch0 >= 0) n0 = noise_from_byte(ns, nw.rw[i0 >> 4][(i0 >> 2) & 3], i0 & 3);
+        if (ch1 >= 0) n1 = noise_from_byte(ns, nw.rw[i1 >> 4][(i1 >> 2) & 3], i1 & 3);
+        xs[s] += h ? n1 : n0;
+    }
 }
 
 // adds the noise of the slot's reference channel (image_compression.py:250: every real channel)
@@ -389,37 +444,9 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
         }
         return;
     }
-    constexpr int NG0 = L::K0 / 2 * kC;              // G0 slots of a half = one channel group (see noise_block)
-    constexpr int GB = (NG0 + 15) / 16;              // blocks per G0 group
-#pragma unroll
-    for (int j = 0; j < GB; ++j) {
-        const U4 b = noise_block(ns, sample_global, GB * h + j);
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (16 * j + t < NG0) xs[16 * j + t] += noise_from_block(ns, b, t);
-    }
-    constexpr int RB0 = 2 * GB;                      // first block of the non-G0 channels
-    constexpr int NREST = L::CIN - L::K0 * kC;
-    constexpr int NRB = (NREST + 15) / 16;
-    // The remaining slots' channels depend on the lane-half, but for EACH half (block, word, byte) of a slot are
-    // compile-time constants: pick both candidates with constant indices and select by h - one v_cndmask per slot, no
-    // branches (a runtime channel index compiles to a divergent branch per slot and block: ~6K cycles per round).
-    uint32_t rw[NRB][4];
-#pragma unroll
-    for (int j = 0; j < NRB; ++j) {
-        const U4 b = noise_block(ns, sample_global, RB0 + j);
-        rw[j][0] = b.x; rw[j][1] = b.y; rw[j][2] = b.z; rw[j][3] = b.w;
-    }
-#pragma unroll
-    for (int s = NG0; s < L::NSLOT; ++s) {
-        const int ch0 = L::slot_channel(s, 0), ch1 = L::slot_channel(s, 1);
-        if (ch0 < 0 && ch1 < 0) continue;
-        const int i0 = ch0 - L::K0 * kC, i1 = ch1 - L::K0 * kC;       // index among the non-G0 channels
-        float n0 = 0.f, n1 = 0.f;
-        if (ch0 >= 0) n0 = noise_from_byte(ns, rw[i0 >> 4][(i0 >> 2) & 3], i0 & 3);
-        if (ch1 >= 0) n1 = noise_from_byte(ns, rw[i1 >> 4][(i1 >> 2) & 3], i1 & 3);
-        xs[s] += h ? n1 : n0;
-    }
+    NoiseWords<L> nw;
+    noise_words<L>(ns, sample_global, h, nw);
+    apply_noise<L>(ns, nw, h, xs);
 }
 
 // Gradients of the lane's grid slots.  Every sample a lane handles inside one macro-tile lies in the same G0 cell (and G1
