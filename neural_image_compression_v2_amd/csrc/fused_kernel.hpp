@@ -385,51 +385,33 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
     }
 }
 
-// The in-kernel generator in two steps: the blocks, then their application to the slots.  (Running the generator between issuing
-// the round's gathers and consuming them was tried: the 64 extra live values spill.)
+// In-kernel noise (NIC_NOISE_KERNEL).  The values of a sample come in two streams, one per lane half: value v of stream h
+// belongs to the v-th REAL slot (slot_channel >= 0) of that half, in slot order - the same v for both halves wherever both are
+// real - and lives in generator block NB * h + (v >> 4), position v & 15.  A lane therefore runs ceil(real slots / 16) blocks
+// (3 in 2D instead of the 4 of a by-channel numbering) and needs no selects.  oracle/nic_oracle.py::kernel_noise restates the
+// (channel -> stream, v) map from the slot layouts.
 template <class L>
-struct NoiseWords {
-    static constexpr int NG0 = L::K0 / 2 * kC;              // G0 slots of a half = one channel group (see noise_block)
-    static constexpr int GB = (NG0 + 15) / 16;              // blocks per G0 group
-    static constexpr int RB0 = 2 * GB;                      // first block of the non-G0 channels
-    static constexpr int NREST = L::CIN - L::K0 * kC;
-    static constexpr int NRB = (NREST + 15) / 16;
-    U4 g[GB];
-    uint32_t rw[NRB][4];
+struct NoiseMap {
+    __host__ __device__ static constexpr int count(int h) {
+        int n = 0;
+        for (int s = 0; s < L::NSLOT; ++s) n += L::slot_channel(s, h) >= 0 ? 1 : 0;
+        return n;
+    }
+    struct Table { int v[2][L::NSLOT]; };                                      // v of slot s in stream h
+    __host__ __device__ static constexpr Table make() {
+        Table t{};
+        for (int h = 0; h < 2; ++h) {
+            int n = 0;
+            for (int s = 0; s < L::NSLOT; ++s) {
+                t.v[h][s] = n;
+                n += L::slot_channel(s, h) >= 0 ? 1 : 0;
+            }
+        }
+        return t;
+    }
+    static constexpr int NV = count(0) > count(1) ? count(0) : count(1);
+    static constexpr int NB = (NV + 15) / 16;                                 // blocks per stream
 };
-template <class L>
-__device__ __forceinline__ void noise_words(const NoiseSrc& ns, uint64_t sample_global, int h, NoiseWords<L>& nw) {
-    using N = NoiseWords<L>;
-#pragma unroll
-    for (int j = 0; j < N::GB; ++j) nw.g[j] = noise_block(ns, sample_global, N::GB * h + j);
-#pragma unroll
-    for (int j = 0; j < N::NRB; ++j) {
-        const U4 b = noise_block(ns, sample_global, N::RB0 + j);
-        nw.rw[j][0] = b.x; nw.rw[j][1] = b.y; nw.rw[j][2] = b.z; nw.rw[j][3] = b.w;
-    }
-}
-template <class L>
-__device__ __forceinline__ void apply_noise(const NoiseSrc& ns, const NoiseWords<L>& nw, int h, float (&xs)[L::NSLOT]) {
-    using N = NoiseWords<L>;
-#pragma unroll
-    for (int j = 0; j < N::GB; ++j)
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (16 * j + t < N::NG0) xs[16 * j + t] += noise_from_block(ns, nw.g[j], t);
-    // The remaining slots' channels depend on the lane-half, but for EACH half (block, word, byte) of a slot are
-    // compile-time constants: pick both candidates with constant indices and select by h - one v_cndmask per slot, no
-    // branches (a runtime channel index compiles to a divergent branch per slot and block: ~6K cycles per round).
-#pragma unroll
-    for (int s = N::NG0; s < L::NSLOT; ++s) {
-        const int ch0 = L::slot_channel(s, 0), ch1 = L::slot_channel(s, 1);
-        if (ch0 < 0 && ch1 < 0) continue;
-        const int i0 = ch0 - L::K0 * kC, i1 = ch1 - L::K0 * kC;       // index among the non-G0 channels
-        float n0 = 0.f, n1 = 0.f;
-        if (ch0 >= 0) n0 = noise_from_byte(ns, nw.rw[i0 >> 4][(i0 >> 2) & 3], i0 & 3);
-        if (ch1 >= 0) n1 = noise_from_byte(ns, nw.rw[i1 >> 4][(i1 >> 2) & 3], i1 & 3);
-        xs[s] += h ? n1 : n0;
-    }
-}
 
 // adds the noise of the slot's reference channel (image_compression.py:250: every real channel)
 template <class L>
@@ -444,9 +426,24 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
         }
         return;
     }
-    NoiseWords<L> nw;
-    noise_words<L>(ns, sample_global, h, nw);
-    apply_noise<L>(ns, nw, h, xs);
+    using M = NoiseMap<L>;
+    constexpr typename M::Table tab = M::make();
+    U4 blk[M::NB];
+#pragma unroll
+    for (int j = 0; j < M::NB; ++j) blk[j] = noise_block(ns, sample_global, M::NB * h + j);
+#pragma unroll
+    for (int s = 0; s < L::NSLOT; ++s) {
+        const bool r0 = L::slot_channel(s, 0) >= 0, r1 = L::slot_channel(s, 1) >= 0;
+        if (!r0 && !r1) continue;
+        const int v0 = tab.v[0][s], v1 = tab.v[1][s];
+        if (r0 && r1 && v0 == v1) {
+            xs[s] += noise_from_block(ns, blk[v0 >> 4], v0 & 15);
+        } else {                                                              // real in one half only, or different positions
+            const float n0 = r0 ? noise_from_block(ns, blk[v0 >> 4], v0 & 15) : 0.f;
+            const float n1 = r1 ? noise_from_block(ns, blk[v1 >> 4], v1 & 15) : 0.f;
+            xs[s] += h ? n1 : n0;
+        }
+    }
 }
 
 // Gradients of the lane's grid slots.  Every sample a lane handles inside one macro-tile lies in the same G0 cell (and G1
