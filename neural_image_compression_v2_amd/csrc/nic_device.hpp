@@ -129,30 +129,33 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 __device__ __forceinline__ void gelu_and_grad4(const f32x4_t z, f32x4_t& a, f32x4_t& d) {
     const f32x2 za = {z[0], z[1]}, zb = {z[2], z[3]};
     constexpr float kP = 0.3275911f * 0.70710678118654752440f, kE = -0.5f * 1.44269504088896340736f;
+    const f32x2 xa = za * (za * f32x2(kE)), xb = zb * (zb * f32x2(kE));      // log2 of exp(-z^2 / 2)
     f32x2 ta, tb, ea, eb;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         ta[i] = __builtin_amdgcn_rcpf(fmaf(kP, fabsf(za[i]), 1.0f));
         tb[i] = __builtin_amdgcn_rcpf(fmaf(kP, fabsf(zb[i]), 1.0f));
-        ea[i] = __builtin_amdgcn_exp2f(za[i] * (za[i] * kE));
-        eb[i] = __builtin_amdgcn_exp2f(zb[i] * (zb[i] * kE));
+        ea[i] = __builtin_amdgcn_exp2f(xa[i]);
+        eb[i] = __builtin_amdgcn_exp2f(xb[i]);
     }
-    f32x2 pa = pk_fma(f32x2(1.061405429f), ta, f32x2(-1.453152027f));
-    f32x2 pb = pk_fma(f32x2(1.061405429f), tb, f32x2(-1.453152027f));
-    pa = pk_fma(pa, ta, f32x2(1.421413741f));
-    pb = pk_fma(pb, tb, f32x2(1.421413741f));
-    pa = pk_fma(pa, ta, f32x2(-0.284496736f));
-    pb = pk_fma(pb, tb, f32x2(-0.284496736f));
-    pa = pk_fma(pa, ta, f32x2(0.254829592f));
-    pb = pk_fma(pb, tb, f32x2(0.254829592f));
+    // Horner with the coefficients halved: (poly * t) * e = (1 - erf(|u|)) / 2 directly
+    f32x2 pa = pk_fma(f32x2(0.5f * 1.061405429f), ta, f32x2(0.5f * -1.453152027f));
+    f32x2 pb = pk_fma(f32x2(0.5f * 1.061405429f), tb, f32x2(0.5f * -1.453152027f));
+    pa = pk_fma(pa, ta, f32x2(0.5f * 1.421413741f));
+    pb = pk_fma(pb, tb, f32x2(0.5f * 1.421413741f));
+    pa = pk_fma(pa, ta, f32x2(0.5f * -0.284496736f));
+    pb = pk_fma(pb, tb, f32x2(0.5f * -0.284496736f));
+    pa = pk_fma(pa, ta, f32x2(0.5f * 0.254829592f));
+    pb = pk_fma(pb, tb, f32x2(0.5f * 0.254829592f));
     pa = pa * ta;
     pb = pb * tb;
-    const f32x2 ha = (pa * f32x2(0.5f)) * ea, hb = (pb * f32x2(0.5f)) * eb;       // (1 - erf(|u|)) / 2
+    // Phi(z) = 1/2 + copysign(1/2 - h, z), h = (1 - erf(|u|)) / 2: no compare / select pair
+    const f32x2 ga = pk_fma(-pa, ea, f32x2(0.5f)), gb = pk_fma(-pb, eb, f32x2(0.5f));
     f32x2 ca, cb;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        ca[i] = za[i] >= 0.f ? 1.0f - ha[i] : ha[i];
-        cb[i] = zb[i] >= 0.f ? 1.0f - hb[i] : hb[i];
+        ca[i] = 0.5f + __builtin_copysignf(ga[i], za[i]);
+        cb[i] = 0.5f + __builtin_copysignf(gb[i], zb[i]);
     }
     const f32x2 aa = za * ca, ab = zb * cb;
     const f32x2 da = pk_fma(za * f32x2(0.39894228040143267794f), ea, ca), db = pk_fma(zb * f32x2(0.39894228040143267794f), eb, cb);
