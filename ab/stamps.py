@@ -13,7 +13,8 @@ if METHOD == 1:
     fp, _ = fp_def.create_pyramid((H // 4, W // 4), 12, 8, dev, torch.float32, True)
     dec = ColorDecoder(73, 64).to(dev)
     geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
-                             noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1)
+                             noise_mode=int(os.environ.get("NOISE", "2")), noise_seed=7, noise_offset=1,
+                             flags=_lib.NIC_FLAG_SPLIT_BF16 if os.environ.get("SPLIT") == "1" else 0)
     org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
 else:
     S = 128

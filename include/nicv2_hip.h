@@ -87,6 +87,11 @@ typedef struct nic_path_desc {
  * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1
  * (origins live on the device, the library cannot look). Setting it for unaligned origins drops samples. */
 #define NIC_FLAG_ORIGINS_ALIGNED 1
+/* nic_fused_forward_backward only, 2D only: the four chained matrix products (layer 1, layer 2 and their input-gradient
+ * transposes) run on the bf16 matrix pipe with every fp32 operand carried as a hi + lo bf16 pair (16 significant bits,
+ * fp32 accumulation; ~1e-5 relative instead of fp32 rounding).  Everything else - weight-gradient products, layer 3,
+ * activations, noise, loss - is unchanged fp32.  NIC_E_UNSUPPORTED elsewhere. */
+#define NIC_FLAG_SPLIT_BF16 2
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */
 typedef struct nic_mlp {

@@ -109,6 +109,78 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// ---- split-bf16 matrix products (PREC_SPLIT): an fp32 operand x is carried as hi + lo, hi = bf16(x), lo = bf16(x - hi) (16
+// significant bits), and a product as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 x 32 cycles per
+// K = 16 instead of 8 x 64 for the fp32 form, and - unlike the fp32 form - the bf16 pipe runs beside the wave's
+// own VALU work.  Operand layouts (checked with exact integer data by ab/micro/bf16_chain.hip): accumulator registers 8s..8s+7
+// of a tile, converted pairwise, are the B fragment of k-step s (element j of lane half g = row 16s + 8(j>>2) + 4g + (j&3));
+// the A fragment of a natural [row][k] bf16 image is two 8-byte reads at k = 16s + 4g and + 8 (row-wise), or two
+// ds_read_b64_tr_b16 of the 4 x 16 blocks at rows 16s + 4g and + 8 (the transposed product), from ONE image.
+enum { PREC_F32 = 0, PREC_SPLIT = 1 };
+// between the k-steps of a split product the scheduler is left free: the next step's operand split (VALU) and LDS reads run
+// beside the current step's bf16 MFMAs (3.51 -> 3.42 ms against a scheduling barrier per step)
+#ifndef NIC_SPLIT_SB
+#define NIC_SPLIT_SB ((void)0)
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) __bf16 lds_bf;
+typedef __attribute__((address_space(3))) const __bf16 lds_cbf;
+typedef __attribute__((address_space(3))) const s16x4 lds_cs16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ lds_cbf* opaque(lds_cbf* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+struct Frag2 {
+    bf16x8 hi, lo;
+};
+// 8 fp32 values -> hi / lo fragments.  x - hi is exact in fp32, so hi + lo carries 16 significant bits of x.
+__device__ __forceinline__ Frag2 split8(const float (&x)[8]) {
+    u32x4 hp, lp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32, RNE
+        const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xFFFF0000u)};
+        hp[i] = h;
+        lp[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    }
+    Frag2 f;
+    f.hi = __builtin_bit_cast(bf16x8, hp);
+    f.lo = __builtin_bit_cast(bf16x8, lp);
+    return f;
+}
+__device__ __forceinline__ Frag2 split_acc(const f32x16& t, int s) {            // registers 8s .. 8s+7 of an accumulator tile
+    const float x[8] = {t[8 * s], t[8 * s + 1], t[8 * s + 2], t[8 * s + 3], t[8 * s + 4], t[8 * s + 5], t[8 * s + 6], t[8 * s + 7]};
+    return split8(x);
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// A fragment, row-wise: p = &image[row][k0 + 4g]; elements k0 + 4g .. + 3 and k0 + 8 + 4g .. + 3
+__device__ __forceinline__ bf16x8 frag_row(lds_cbf* p) {
+    return join8(*reinterpret_cast<lds_cs16x4*>(p), *reinterpret_cast<lds_cs16x4*>(p + 8));
+}
+// A fragment of the transposed product: p = &image[r0 + 4g + q][c0 + 16cg + 4p'] (lane 4q + p' of its 16-lane group), ld = row stride
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_tr(lds_cbf* p) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * LD));
+    return join8(a, b);
+}
+// acc += A (hi, lo) x B (hi, lo) without the lo x lo term (2^-18 relative)
+__device__ __forceinline__ f32x16 mfma_split(const Frag2& a, const Frag2& b, f32x16 c) {
+    c = mfma_bf(a.lo, b.hi, c);
+    c = mfma_bf(a.hi, b.lo, c);
+    return mfma_bf(a.hi, b.hi, c);
+}
+
 // LDS traffic between lanes of ONE wave: DS operations of a wave complete in order, so only the
 // compiler has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -538,10 +610,12 @@ __device__ __forceinline__ void flush_grid_grads(const FusedParams& p, uint32_t 
 }
 
 // =====================================================================================================
-template <class L, int SRC, int MODE, class GT = float>
+template <class L, int SRC, int MODE, class GT = float, int PREC = PREC_F32>
 __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(FusedParams p) {
     using S = Lds<L>;
     constexpr bool TRAIN = MODE != MODE_INFER;
+    constexpr bool SPLIT = PREC == PREC_SPLIT;
+    static_assert(!SPLIT || L::NSLOT % 8 == 0, "split-bf16 k-steps cover 8 slots");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
     __shared__ __attribute__((aligned(16))) float smem[TRAIN ? S::TOTAL_TRAIN : S::TOTAL_INFER];
     lds_f* const sm = (lds_f*)smem;
@@ -556,6 +630,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 
     // ---------------- prologue: decoder weights -> LDS (first layer permuted into slot order, bias in the
     // column of the constant-one slot), scratch zeroed
+    // SPLIT: the same two regions hold bf16 hi / lo images ([64][LD] elements each, natural row / column order) instead
+    lds_bf* const W1b = (lds_bf*)W1s;
+    lds_bf* const W2b = (lds_bf*)W2s;
     for (int idx = tid; idx < kH * LD1; idx += 256) {
         const int o = idx / LD1, rho = idx - o * LD1;
         float v = 0.f;
@@ -564,11 +641,24 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             if (ch >= 0) v = p.W[0][o * L::CIN + ch];
             else if (ch == kSlotOne) v = p.b[0][o];
         }
-        W1s[idx] = v;
+        if (SPLIT) {
+            const __bf16 hi = (__bf16)v;
+            W1b[idx] = hi;
+            W1b[kH * LD1 + idx] = (__bf16)(v - (float)hi);
+        } else {
+            W1s[idx] = v;
+        }
     }
     for (int idx = tid; idx < kH * LD2; idx += 256) {
         const int o = idx / LD2, k = idx - o * LD2;
-        W2s[idx] = k < kH ? p.W[1][o * kH + k] : 0.f;
+        const float v = k < kH ? p.W[1][o * kH + k] : 0.f;
+        if (SPLIT) {
+            const __bf16 hi = (__bf16)v;
+            W2b[idx] = hi;
+            W2b[kH * LD2 + idx] = (__bf16)(v - (float)hi);
+        } else {
+            W2s[idx] = v;
+        }
     }
     for (int idx = tid; idx < 4 * LD2; idx += 256) {
         const int o = idx / LD2, k = idx - o * LD2;
@@ -673,6 +763,15 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         lds_cf* const sa_lane = opaque(SA + lane * LDT);            // row passes: lane walks row `lane`
         lds_cf* const sb_lane = opaque(SB + lane * LDT);
         lds_cf* const sa_bc = opaque(SA);                           // broadcast reads of rows 0..2
+        // SPLIT: row-wise fragments [row pl][k + 4h]; transposed fragments: lane 4q + p' of its 16-lane group points at
+        // [row 4h + q][col 16 cg + 4 p'] (cg = which half of the 32 output rows the group covers)
+        lds_cbf* w1b_row = nullptr, *w2b_row = nullptr, *w1b_tr = nullptr, *w2b_tr = nullptr;
+        if constexpr (SPLIT) {
+            w1b_row = opaque((lds_cbf*)W1b + pl * LD1 + 4 * h);
+            w2b_row = opaque((lds_cbf*)W2b + pl * LD2 + 4 * h);
+            w1b_tr = opaque((lds_cbf*)W1b + (4 * h + ((lane & 15) >> 2)) * LD1 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+            w2b_tr = opaque((lds_cbf*)W2b + (4 * h + ((lane & 15) >> 2)) * LD2 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+        }
 
         // ---------- which sample does this lane own in this round
         bool valid;
@@ -748,6 +847,22 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 a1[2], d1[2];
         {
             f32x16 z[2] = {f32x16(0.f), f32x16(0.f)};
+            if constexpr (SPLIT) {
+                // k-step b = slots 8b .. 8b+7 of both lane halves = internal rows 16b + 8(j>>2) + 4g + (j&3)
+#pragma unroll
+                for (int b = 0; b < L::NSLOT / 8; ++b) {
+                    const float xv[8] = {xs[8 * b], xs[8 * b + 1], xs[8 * b + 2], xs[8 * b + 3], xs[8 * b + 4], xs[8 * b + 5], xs[8 * b + 6], xs[8 * b + 7]};
+                    const Frag2 bf = split8(xv);
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        Frag2 af;
+                        af.hi = frag_row(&w1b_row[32 * to * LD1 + 16 * b]);
+                        af.lo = frag_row(&w1b_row[kH * LD1 + 32 * to * LD1 + 16 * b]);
+                        z[to] = mfma_split(af, bf, z[to]);
+                    }
+                    NIC_SPLIT_SB;
+                }
+            } else {
             // every MFMA phase fetches its LDS operands one step (4 MFMAs) ahead, so the LDS latency of step i + 1 runs
             // under the MFMAs of step i instead of in front of them
             constexpr int NST = 2 * (L::NSLOT / 4);                     // step = (4 slots, one row tile)
@@ -768,6 +883,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     z[to] = mfma32(aq[st & 1][j], xs[sig + j], z[to]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
 #pragma unroll
             for (int to = 0; to < 2; ++to)
@@ -797,6 +913,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[to][4 * r4 + j] = bb[j];
                 }
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                         // k-step (t, s): hidden rows 32t + 16s + ..
+                    const Frag2 bf = split_acc(a1[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        Frag2 af;
+                        af.hi = frag_row(&w2b_row[32 * to * LD2 + 16 * ks]);
+                        af.lo = frag_row(&w2b_row[kH * LD2 + 32 * to * LD2 + 16 * ks]);
+                        z[to] = mfma_split(af, bf, z[to]);
+                    }
+                    NIC_SPLIT_SB;
+                }
+            } else {
             auto w2_at = [&](int st) { return ld4(&w2_row[32 * (st & 1) * LD2 + 32 * (st >> 3) + 8 * ((st >> 1) & 3)]); };
             f32x4 aq[2];
             aq[0] = w2_at(0);
@@ -807,6 +937,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) z[to] = mfma32(aq[st & 1][j], a1[t][4 * r4 + j], z[to]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // layer 3 rides along: only 3 outputs - a 32-row MFMA tile would be 90 % padding, so each lane dots its 32 hidden
             // values with the matching W3 columns (broadcast LDS reads, issued before the group's GELU so their latency runs
@@ -956,6 +1087,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 dz1[2];
         {
             f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                         // contraction rows o = 16 ks + ..
+                    const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tk = 0; tk < 2; ++tk) {
+                        Frag2 af;
+                        af.hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
+                        af.lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
+                        acc[tk] = mfma_split(af, bf, acc[tk]);
+                    }
+                    NIC_SPLIT_SB;
+                }
+            } else {
             // A operands (columns of W2) are fetched one step (2 k-steps = 4 MFMAs) ahead: the LDS latency of step i + 1
             // runs under the MFMAs of step i instead of in front of them
             float wq[2][4];
@@ -980,6 +1125,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     for (int tk = 0; tk < 2; ++tk) acc[tk] = mfma32(wq[st & 1][2 * u + tk], dz2[rr >> 4][rr & 15], acc[tk]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             dz1[0] = acc[0] * d1[0];
             dz1[1] = acc[1] * d1[1];
@@ -1104,6 +1250,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 dxacc[NGT];
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tg = 0; tg < NGT; ++tg) {
+                        Frag2 af;
+                        af.hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
+                        af.lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
+                        dxacc[tg] = mfma_split(af, bf, dxacc[tg]);
+                    }
+                    NIC_SPLIT_SB;
+                }
+            } else {
             // same one-step-ahead operand fetch as dA1
             float wq[2][2 * NGT];
 #pragma unroll
@@ -1127,6 +1287,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma32(wq[st & 1][NGT * u + tg], dz1[rr >> 4][rr & 15], dxacc[tg]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             if (SRC == SRC_ENCODE) {
                 accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc);        // masked lanes carry exact zeros (dZ3 = 0)

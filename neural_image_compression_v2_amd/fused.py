@@ -118,6 +118,8 @@ class PathGeometry:
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
+        if os.environ.get("NIC_FORCE_SPLIT_BF16") == "1" and self.dim == 2:      # test switch: run every 2D training step in split-bf16
+            d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         return d
 
 
