@@ -100,6 +100,14 @@ struct Lds {
     static constexpr bool PART16 = PART && XIMG && (KPAD - 32 * (KT - 1) <= 16);
     static constexpr int NSLOT_REC = NACC + (PART ? (PART16 ? 4 : 8) : 0);   // + per-wave partial tiles: [4][1024] or [4][2][1024]
     static constexpr int REC = NSLOT_REC * 1024 + 4 * 320;    // floats per WORKGROUP record; tails per wave: db2, dW3, db3, loss
+    // PREC_SPLIT: the wave-private region holds bf16 images with the SAMPLE as the row (32 rows), hi and lo of each: DZ (a2, then
+    // dZ2, then dZ1: 64 columns), A1 (64 columns), X (KPAD columns), and dZ3 as [4][32].  Every consumer reads them with
+    // ds_read_b64_tr_b16 (sizes in bf16 elements).
+    static constexpr int LDZB = kH + 8, LDXB = KPAD + 8;
+    static constexpr int BZ = 32 * LDZB, BX = 32 * LDXB;
+    static constexpr int SPW = 4 * BZ + 2 * BX + 256;         // per wave
+    static constexpr int TOTAL_SPLIT = OFF_SCR + 4 * SPW / 2;
+    static_assert(SPW % 8 == 0, "16-byte aligned wave regions");
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -174,6 +182,14 @@ __device__ __forceinline__ bf16x8 frag_tr(lds_cbf* p) {
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * LD));
     return join8(a, b);
 }
+__device__ __forceinline__ void store_frag(lds_bf* p, const bf16x8& f) {        // elements 0..3 at p, 4..7 at p + 8
+    const s16x8 v = __builtin_bit_cast(s16x8, f);
+    *reinterpret_cast<lds_s16x4*>(p) = s16x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<lds_s16x4*>(p + 8) = s16x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ s16x4 tr4(lds_cbf* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p); }
+__device__ __forceinline__ f32x4 mfma16_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma4_bf(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
 // acc += A (hi, lo) x B (hi, lo) without the lo x lo term (2^-18 relative)
 __device__ __forceinline__ f32x16 mfma_split(const Frag2& a, const Frag2& b, f32x16 c) {
     c = mfma_bf(a.lo, b.hi, c);
@@ -615,9 +631,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     using S = Lds<L>;
     constexpr bool TRAIN = MODE != MODE_INFER;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
+    constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : Lds<L>::KT;     // dX row tiles: the grid slots / every slot
     static_assert(!SPLIT || L::NSLOT % 8 == 0, "split-bf16 k-steps cover 8 slots");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
-    __shared__ __attribute__((aligned(16))) float smem[TRAIN ? S::TOTAL_TRAIN : S::TOTAL_INFER];
+    static_assert(!SPLIT || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 layout is built for the 2D slot layouts");
+    __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : S::TOTAL_INFER];
     lds_f* const sm = (lds_f*)smem;
     lds_f* const W1s = sm + S::OFF_W1;
     lds_f* const W2s = sm + S::OFF_W2;
@@ -667,7 +685,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     if (tid < kH) B2s[tid] = p.b[1][tid];
     if (tid < 16) B3s[tid] = tid < 3 ? p.b[2][tid] : 0.f;
     if (TRAIN)
-        for (int idx = tid; idx < S::TOTAL_TRAIN - S::OFF_SCR; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
+        for (int idx = tid; idx < (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) - S::OFF_SCR; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
     __syncthreads();
     lds_f* const SCR0 = sm + S::OFF_SCR;                        // wave 0's scratch; wave w's is SCR_PER_WAVE * w further
 
@@ -687,6 +705,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     accW1p[0] = accW1p[1] = f32x16(0.f);
     float accW3[3] = {0.f, 0.f, 0.f};     // dW3[c][k = lane]
     float accB2 = 0.f;                    // db2[o = lane]
+    f32x4 accW3q = f32x4(0.f), accB2q = f32x4(0.f);   // SPLIT: the same from 4x4x4 MFMAs (register c of lane k / every register of lane o)
     float accB3[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
     const int to2 = wave >> 1, tk2 = wave & 1;                  // ownership
     const int to1 = wave & 1, tk1 = wave >> 1;
@@ -766,6 +785,27 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // SPLIT: row-wise fragments [row pl][k + 4h]; transposed fragments: lane 4q + p' of its 16-lane group points at
         // [row 4h + q][col 16 cg + 4 p'] (cg = which half of the 32 output rows the group covers)
         lds_cbf* w1b_row = nullptr, *w2b_row = nullptr, *w1b_tr = nullptr, *w2b_tr = nullptr;
+        // SPLIT images (see Lds<>): store bases [sample pl][4h ..] of the wave's own images; transposed-read bases of wave 0's
+        // images for the 32x32x16 fragments (lane 4q + p' of a 16-lane group: [row 4h + q][col 16 cg + 4 p']), of the wave's own
+        // images for the 16x16x32 fragments ([row 8 (lane >> 4) + q][col 4 p']) and the 4x4x4 B operand ([row q][col 16 (lane >> 4) + 4 p'])
+        lds_bf* dz_st = nullptr, *a1_st = nullptr, *x_st = nullptr, *d3_st = nullptr;
+        lds_cbf* dz_tr = nullptr, *a1_tr = nullptr, *x_tr = nullptr, *dz_p16 = nullptr, *x_p16 = nullptr, *dz_b44 = nullptr, *d3_a44 = nullptr;
+        if constexpr (SPLIT && TRAIN) {
+            lds_bf* const img0 = (lds_bf*)(sm + S::OFF_SCR);
+            lds_bf* const imgw = img0 + wave * S::SPW;
+            const int q4 = (lane & 15) >> 2, p4 = lane & 3, cg = (lane >> 4) & 1, g16 = lane >> 4;
+            dz_st = (lds_bf*)opaque((lds_cbf*)(imgw + pl * S::LDZB + 4 * h));
+            a1_st = dz_st + 2 * S::BZ;
+            x_st = (lds_bf*)opaque((lds_cbf*)(imgw + 4 * S::BZ + pl * S::LDXB + 4 * h));
+            d3_st = (lds_bf*)opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + pl));
+            dz_tr = opaque((lds_cbf*)(img0 + (4 * h + q4) * S::LDZB + 16 * cg + 4 * p4));
+            a1_tr = dz_tr + 2 * S::BZ;
+            x_tr = opaque((lds_cbf*)(img0 + 4 * S::BZ + (4 * h + q4) * S::LDXB + 16 * cg + 4 * p4));
+            dz_p16 = opaque((lds_cbf*)(imgw + (8 * g16 + q4) * S::LDZB + 4 * p4));
+            x_p16 = opaque((lds_cbf*)(imgw + 4 * S::BZ + (8 * g16 + q4) * S::LDXB + 32 * (KT - 1) + 4 * p4));
+            dz_b44 = opaque((lds_cbf*)(imgw + q4 * S::LDZB + 16 * g16 + 4 * p4));
+            d3_a44 = opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + (lane & 3) * 32));
+        }
         if constexpr (SPLIT) {
             w1b_row = opaque((lds_cbf*)W1b + pl * LD1 + 4 * h);
             w2b_row = opaque((lds_cbf*)W2b + pl * LD2 + 4 * h);
@@ -837,7 +877,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
 
         STAMP(0);    // coordinates, gathers, blend, PE, noise
-        if (TRAIN && S::XIMG) {
+        if (TRAIN && S::XIMG && !SPLIT) {
             // permanent transposed image of X for dW1 (read by all four waves after the round's barriers)
             lds_f* const xi_st = opaque(sm + S::OFF_XIMG + wave * S::XIMG_PER_WAVE + 4 * h * LDT + pl);
 #pragma unroll
@@ -853,6 +893,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 for (int b = 0; b < L::NSLOT / 8; ++b) {
                     const float xv[8] = {xs[8 * b], xs[8 * b + 1], xs[8 * b + 2], xs[8 * b + 3], xs[8 * b + 4], xs[8 * b + 5], xs[8 * b + 6], xs[8 * b + 7]};
                     const Frag2 bf = split8(xv);
+                    if (TRAIN) {                                         // the X image of the weight-gradient product: columns 16b + 4h.. and + 8
+                        store_frag(&x_st[16 * b], bf.hi);
+                        store_frag(&x_st[S::BX + 16 * b], bf.lo);
+                    }
 #pragma unroll
                     for (int to = 0; to < 2; ++to) {
                         Frag2 af;
@@ -917,6 +961,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {                         // k-step (t, s): hidden rows 32t + 16s + ..
                     const Frag2 bf = split_acc(a1[ks >> 1], ks & 1);
+                    if (TRAIN) {
+                        store_frag(&a1_st[16 * ks], bf.hi);
+                        store_frag(&a1_st[S::BZ + 16 * ks], bf.lo);
+                    }
 #pragma unroll
                     for (int to = 0; to < 2; ++to) {
                         Frag2 af;
@@ -995,6 +1043,154 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 accB3[c] += dz3[c];
             }
         }
+        if constexpr (SPLIT && SRC == SRC_ENCODE) {
+        // ================= split-bf16 backward: every product on the bf16 matrix pipe, operands from the [sample][feature] images
+        // ---------- a2 -> the DZ region (free until dZ2 is stored), dZ3 -> its [c][s] image
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const Frag2 f = split_acc(a2[ks >> 1], ks & 1);
+            store_frag(&dz_st[16 * ks], f.hi);
+            store_frag(&dz_st[S::BZ + 16 * ks], f.lo);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const __bf16 hi = (__bf16)dz3[c];
+                d3_st[c * 32] = hi;
+                d3_st[128 + c * 32] = (__bf16)(dz3[c] - (float)hi);
+            }
+        }
+        wave_lds_fence();
+        // ---------- dW3[c][k = lane] += sum_s dZ3[c][s] A2[k][s]: 4x4x4 MFMAs (16 blocks of 4 columns: lane l <-> column l),
+        // A = dZ3[c = lane & 3][4 samples] (the same in every block), B = column l of 4 sample rows of the a2 image
+#pragma unroll
+        for (int s0 = 0; s0 < 32; s0 += 4) {
+            const s16x4 bh = tr4(&dz_b44[s0 * S::LDZB]), bl = tr4(&dz_b44[S::BZ + s0 * S::LDZB]);
+            const s16x4 ah = *reinterpret_cast<lds_cs16x4*>(&d3_a44[s0]), al = *reinterpret_cast<lds_cs16x4*>(&d3_a44[128 + s0]);
+            accW3q = mfma4_bf(al, bh, accW3q);
+            accW3q = mfma4_bf(ah, bl, accW3q);
+            accW3q = mfma4_bf(ah, bh, accW3q);
+        }
+        // ---------- dA2 = W3^T dZ3 (K = 3, padded to 4; fp32 MFMA), dZ2 = dA2 * gelu'(Z2)
+        f32x16 dz2[2];
+        {
+            const float s1 = __shfl(dz3[1], pl);
+            const float b0 = h ? s1 : dz3[0];
+            const float b1 = h ? 0.f : dz3[2];
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk) {
+                f32x16 acc = f32x16(0.f);
+                acc = mfma32(w3_col[32 * tk], b0, acc);
+                acc = mfma32(w3_col[2 * LD2 + 32 * tk], b1, acc);
+                dz2[tk] = acc * d2[tk];
+            }
+        }
+        STAMP(2);    // a2 / dZ3 images, dW3, dA2
+        wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
+        // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are also the dZ2 image of the weight-gradient product
+        f32x16 dz1[2];
+        {
+            f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
+                store_frag(&dz_st[16 * ks], bf.hi);
+                store_frag(&dz_st[S::BZ + 16 * ks], bf.lo);
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk) {
+                    Frag2 af;
+                    af.hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
+                    af.lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
+                    acc[tk] = mfma_split(af, bf, acc[tk]);
+                }
+            }
+            dz1[0] = acc[0] * d1[0];
+            dz1[1] = acc[1] * d1[1];
+        }
+        wave_lds_fence();
+        // ---------- db2[o = lane] += sum_s dZ2[o][s]: 4x4x4 MFMAs against a block of ones (every output row is the column sum)
+        {
+            const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+            for (int s0 = 0; s0 < 32; s0 += 4) {
+                accB2q = mfma4_bf(ones, tr4(&dz_b44[S::BZ + s0 * S::LDZB]), accB2q);
+                accB2q = mfma4_bf(ones, tr4(&dz_b44[s0 * S::LDZB]), accB2q);
+            }
+        }
+        STAMP(3);    // dA1 (+ dZ2 image), db2
+        wg_lds_barrier();
+        STAMP(4);    // wait at barrier 1
+        // ---------- dW2 tile (to2, tk2) += sum over the four waves' samples of dZ2[o][s] A1[k][s]
+#pragma unroll
+        for (int ksw = 0; ksw < 8; ++ksw) {                            // k-step = (source wave, 16 samples)
+            const int off = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDZB;
+            Frag2 af, bf;
+            af.hi = frag_tr<S::LDZB>(&dz_tr[off + 32 * to2]);
+            af.lo = frag_tr<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
+            bf.hi = frag_tr<S::LDZB>(&a1_tr[off + 32 * tk2]);
+            bf.lo = frag_tr<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
+            accW2o = mfma_split(af, bf, accW2o);
+        }
+        STAMP(5);    // dW2 MFMAs (owned tile, 4 sources)
+        wg_lds_barrier();                                              // everyone is done reading dZ2 before dZ1 replaces it
+        STAMP(6);    // wait at barrier 2
+        // ---------- dX = W1p^T dZ1 for the grid slots; the split dZ1 fragments are the dZ1 image
+        {
+            f32x16 dxacc[NGT];
+#pragma unroll
+            for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
+                store_frag(&dz_st[16 * ks], bf.hi);
+                store_frag(&dz_st[S::BZ + 16 * ks], bf.lo);
+#pragma unroll
+                for (int tg = 0; tg < NGT; ++tg) {
+                    Frag2 af;
+                    af.hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
+                    af.lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
+                    dxacc[tg] = mfma_split(af, bf, dxacc[tg]);
+                }
+            }
+            accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc);            // masked lanes carry exact zeros (dZ3 = 0)
+        }
+        STAMP(7);    // dX (+ dZ1 image), grid-gradient accumulation
+        wg_lds_barrier();
+        STAMP(8);    // wait at barrier 3
+        // ---------- dW1 tiles (to1, 2c + tk1) += sum over the four waves' samples of dZ1[o][s] X[rho][s]
+#pragma unroll
+        for (int c2 = 0; c2 < NCH; ++c2) {
+#pragma unroll
+            for (int ksw = 0; ksw < 8; ++ksw) {
+                const int offz = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDZB, offx = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDXB;
+                Frag2 af, bf;
+                af.hi = frag_tr<S::LDZB>(&dz_tr[offz + 32 * to1]);
+                af.lo = frag_tr<S::LDZB>(&dz_tr[offz + S::BZ + 32 * to1]);
+                bf.hi = frag_tr<S::LDXB>(&x_tr[offx + 64 * c2 + 32 * tk1]);
+                bf.lo = frag_tr<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
+                accW1o[c2] = mfma_split(af, bf, accW1o[c2]);
+            }
+        }
+        // odd last col tile (16 real rows): 16x16x32 over this wave's own 32 samples, 4 row tiles of 16
+        {
+            auto frag16 = [&](lds_cbf* ptr, int ld) { return join8(tr4(ptr), tr4(ptr + 4 * ld)); };
+            Frag2 bf;
+            bf.hi = frag16(&x_p16[0], S::LDXB);
+            bf.lo = frag16(&x_p16[S::BX], S::LDXB);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                Frag2 af;
+                af.hi = frag16(&dz_p16[16 * ot], S::LDZB);
+                af.lo = frag16(&dz_p16[S::BZ + 16 * ot], S::LDZB);
+                accW1q[ot] = mfma16_bf(af.lo, bf.hi, accW1q[ot]);
+                accW1q[ot] = mfma16_bf(af.hi, bf.lo, accW1q[ot]);
+                accW1q[ot] = mfma16_bf(af.hi, bf.hi, accW1q[ot]);
+            }
+        }
+        STAMP(9);    // dW1 MFMAs (owned + partial tiles)
+        wg_lds_barrier();                  // all reads of dZ1 / X done before the next round overwrites them
+        STAMP(10);   // wait at barrier 4
+        } else {
         // ---------- dW3[c][k] += sum_s dZ3[c][s] A2[k][s]: lane k walks row k of the transposed A2 image
         if (h == 0) {
 #pragma unroll
@@ -1245,7 +1441,6 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---------- dX = W1p^T dZ1 for the slots that need it
-        constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : KT;
         if (SRC == SRC_ENCODE || p.dx != nullptr) {
             f32x16 dxacc[NGT];
 #pragma unroll
@@ -1300,6 +1495,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 }
             }
         }
+        }
         STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
         if (SRC == SRC_ENCODE && TRAIN) {
@@ -1342,9 +1538,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
     }
     float* tail = rec + S::NSLOT_REC * 1024 + wave * 320;
-    tail[lane] = accB2;
+    tail[lane] = SPLIT ? accB2q[0] : accB2;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) tail[64 + 64 * c + lane] = accW3[c];
+    for (int c = 0; c < 3; ++c) tail[64 + 64 * c + lane] = SPLIT ? accW3q[c] : accW3[c];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float v = c < 3 ? accB3[c] : accLoss;
