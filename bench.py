@@ -30,6 +30,7 @@ CIN, HID = 73, 64
 FLOP_PER_SAMPLE = 6 * (CIN * HID + HID * HID + 3 * HID)          # fwd + bwd MACs x 2 = 53,760
 BYTES_PER_SAMPLE = 8 * 12 * 4 + 2 * 8 * 12 * 4 + 3 * 4            # SURVEY 8d, fp32 params / fp32 grads / fp32 target = 1,164
 PEAK_FP32_MATRIX_TFLOPS = 157.3                                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_TFLOPS = 2500.0                                        # dense bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -75,6 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["split", "f32"], default="split",
+                    help="split: every matrix product of the step as hi + lo bf16 pairs on the bf16 matrix pipe, fp32 accumulate (gradients "
+                         "within 5e-6 of the fp32 kernel; the product's default for 2D training); f32: v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
                     help="tensor: resident fp32 [N,3] targets (the reference's crop stack, built once); image: targets read from the "
                          "resident uint8 image inside the step (a quarter of the bytes, ~3 %% more kernel time: three byte gathers)")
@@ -120,7 +124,8 @@ def main():
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
                                  sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global),
-                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED)  # origin (0, 0)
+                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origin (0, 0)
+                                 split_bf16=args.precision == "split")
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
         all_reduce_flat(out.flat)                                     # RCCL sum of [loss | decoder grads | grid grads]
         cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))  # CosineAnnealingLR(T_max), eta_min = 0
@@ -167,19 +172,28 @@ def main():
             "metric": "Mpixels/sec train-step (fwd+bwd) + PSNR, 4K RGB, 1/2/4/8 MI355X",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "bf16x2-split operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": "3840x2160 RGB fit, every pixel once per step: dense G0 [12,961,541] + G1 [12,481,271] grid pair "
                                    "(reference semantics, no-mip), triangular PE, 3xLinear(64) GELU decoder, in-kernel Threefry-4x32-12 noise, MSE, "
                                    "fused fwd+bwd + grad all-reduce + Adam + clamp",
                        "pixels_per_step_per_gpu": n_local, "parallelism": f"dp{world} (sample-sharded, replicated parameters)",
                        "final_loss": round(loss, 6)},
-            "roofline": {"bound": "mfma", "achieved": round(flops, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flops / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE>", "kernel_ms": round(kern_ms, 4),
-                         "flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": n_local,
-                         "hbm_algorithmic": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                             "bytes_per_sample": BYTES_PER_SAMPLE}},
         }
+        common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,
+                  "samples_per_launch": n_local}
+        hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        if args.precision == "f32":
+            # fp32: the matrix pipe is the tighter roofline (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s vs HBM 8 TB/s / 1 164 B = 6.9 Gpx/s)
+            res["roofline"] = {"bound": "mfma", "achieved": round(flops, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(flops / PEAK_FP32_MATRIX_TFLOPS, 4), **common,
+                               "kernel": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_F32>", "hbm_algorithmic": hbm}
+        else:
+            # split bf16: three bf16 MFMAs per product -> matrix ceiling 2 500 / (3 x 53 760) = 15.5 Gpx/s; the algorithmic-HBM ceiling
+            # (6.9 Gpx/s) is the tighter one, so it is the reported bound; the matrix-pipe figures ride beside it
+            res["roofline"] = {"bound": "hbm", **hbm, **common,
+                               "kernel": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_SPLIT>",
+                               "mfma_bf16": {"achieved_executed": round(3 * flops, 1), "achieved_algorithmic": round(flops, 2),
+                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac_executed": round(3 * flops / PEAK_BF16_TFLOPS, 4)}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(img)
         print(json.dumps(res), flush=True)

@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     constexpr bool TRAIN = MODE != MODE_INFER;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : Lds<L>::KT;     // dX row tiles: the grid slots / every slot
-    static_assert(!SPLIT || L::NSLOT % 8 == 0, "split-bf16 k-steps cover 8 slots");
+    static_assert(!SPLIT || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE && TRAIN), "split-bf16: training from the grids, k-steps of 8 slots");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
     static_assert(!SPLIT || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 layout is built for the 2D slot layouts");
     __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : S::TOTAL_INFER];
@@ -1283,20 +1283,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 dz1[2];
         {
             f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
-            if constexpr (SPLIT) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {                         // contraction rows o = 16 ks + ..
-                    const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
-#pragma unroll
-                    for (int tk = 0; tk < 2; ++tk) {
-                        Frag2 af;
-                        af.hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
-                        af.lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
-                        acc[tk] = mfma_split(af, bf, acc[tk]);
-                    }
-                    NIC_SPLIT_SB;
-                }
-            } else {
+            {
             // A operands (columns of W2) are fetched one step (2 k-steps = 4 MFMAs) ahead: the LDS latency of step i + 1
             // runs under the MFMAs of step i instead of in front of them
             float wq[2][4];
@@ -1445,20 +1432,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 dxacc[NGT];
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
-            if constexpr (SPLIT) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
-#pragma unroll
-                    for (int tg = 0; tg < NGT; ++tg) {
-                        Frag2 af;
-                        af.hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
-                        af.lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
-                        dxacc[tg] = mfma_split(af, bf, dxacc[tg]);
-                    }
-                    NIC_SPLIT_SB;
-                }
-            } else {
+            {
             // same one-step-ahead operand fetch as dA1
             float wq[2][2 * NGT];
 #pragma unroll

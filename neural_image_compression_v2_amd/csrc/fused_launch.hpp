@@ -30,10 +30,12 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
             if (mode == MODE_INFER && p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t>), g, b, 0, s, p); \
             else if (p.grid_u8) return NIC_E_UNSUPPORTED;                                                               \
             else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);   \
-            else if (mode == MODE_TRAIN_MSE && (p.d.flags & NIC_FLAG_SPLIT_BF16)) {                                      \
-                if constexpr (L::NSLOT % 8 == 0 && L::DIM == 2)                                                          \
-                    hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_SPLIT>), g, b, 0, s, p); \
-                else return NIC_E_UNSUPPORTED;                                                                          \
+            else if (p.d.flags & NIC_FLAG_SPLIT_BF16) {                          /* training kernels, 2D layouts */      \
+                if constexpr (L::NSLOT % 8 == 0 && L::DIM == 2) {                                                        \
+                    if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_SPLIT>), g, b, 0, s, p); \
+                    else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_IMG, float, PREC_SPLIT>), g, b, 0, s, p); \
+                    else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY, float, PREC_SPLIT>), g, b, 0, s, p); \
+                } else return NIC_E_UNSUPPORTED;                                                                        \
             }                                                                                                            \
             else if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE>), g, b, 0, s, p); \
             else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_IMG>), g, b, 0, s, p); \

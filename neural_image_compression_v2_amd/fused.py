@@ -65,6 +65,7 @@ class PathGeometry:
     sample_base: int = 0
     loss_scale: Optional[float] = None   # default 1 / (3 N)
     flags: int = 0                       # NIC_FLAG_* the caller vouches for (the wrappers add ORIGINS_ALIGNED when they can see it)
+    split_bf16: bool = False             # 2D training steps: matrix products as hi + lo bf16 pairs on the bf16 pipe (NIC_FLAG_SPLIT_BF16)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -118,7 +119,7 @@ class PathGeometry:
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
-        if os.environ.get("NIC_FORCE_SPLIT_BF16") == "1" and self.dim == 2:      # test switch: run every 2D training step in split-bf16
+        if self.split_bf16 or (os.environ.get("NIC_FORCE_SPLIT_BF16") == "1" and self.dim == 2):   # env: test switch for the whole suite
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         return d
 

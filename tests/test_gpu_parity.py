@@ -278,6 +278,60 @@ def test_fused_forward_backward_matches_oracle(dev, case):
             assert_rel(a, b, 1e-5, "decoder grads run to run")
 
 
+@pytest.mark.parametrize("case", [c for c in FUSED_CASES if c[0] == 2], ids=lambda c: f"split-{c[3]}-{'x'.join(map(str, c[4]))}-{c[6]}".replace(" ", ""))
+def test_split_bf16_training_step(dev, case):
+    """NIC_FLAG_SPLIT_BF16 (every matrix product of the 2D training step as hi + lo bf16 pairs on the bf16 matrix pipe) against
+    the CPU oracle at the SAME tolerances as the fp32 kernel, and against the fp32 kernel itself (outputs 2e-6, gradients 2e-5);
+    all three training entry points (MSE on a target tensor, MSE on the resident image, incoming dY)."""
+    from neural_image_compression_v2_amd import _lib, fused
+    dim, method, tri, base, extent, origins, noise_kind = case
+    fl, mip = 0, 0
+    if isinstance(base, tuple):
+        base, fl, mip = base
+    fp, _ = _pyramid(dim, base, 12, seed=9, no_mip=(mip == 0))
+    g0, g1 = fp[2 * fl], fp[2 * fl + 1]
+    step = O.step_number_of(mip, fl)
+    g = torch.Generator().manual_seed(78)
+    mlp = O.init_mlp(73, 64, generator=g)
+    n = len(origins) * int(np.prod(extent))
+    target = torch.rand(n, 3, generator=g)
+    noise, kw = None, {}
+    if noise_kind == "tensor":
+        noise = (torch.rand(n, 73, generator=g) - 0.5) / 256
+        kw = dict(noise_mode=_lib.NIC_NOISE_TENSOR)
+    elif noise_kind == "kernel":
+        noise = O.kernel_noise(n, 73, 8, seed=5, offset=6)
+        kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5, noise_offset=6)
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, step, mip, target, noise, 6, method=1, use_tri_pe=tri)
+    params = [q.to(dev) for q in mlp.tensors()]
+    nd = noise.to(dev) if noise_kind == "tensor" else None
+    outs = {}
+    for split in (False, True):
+        geo = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                                 split_bf16=split, **kw)
+        outs[split] = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd, want_y=True)
+    out, f32 = outs[True], outs[False]
+    assert_rel(out.y, ref.y, 5e-6, "y")
+    assert_rel(out.loss, ref.loss, 1e-5, "loss")
+    assert_rel(out.grad_g0, ref.grad_g0, 1e-4, "grad G0")
+    assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "grad G1")
+    for nme, a, b in zip(["W1", "b1", "W2", "b2", "W3", "b3"], out.grad_mlp, ref.grad_mlp):
+        assert_rel(a, b, 1e-4, nme)
+    assert_rel(out.y, f32.y, 2e-6, "y vs the fp32 kernel")
+    for a, b in zip([out.grad_g0, out.grad_g1] + out.grad_mlp, [f32.grad_g0, f32.grad_g1] + f32.grad_mlp):
+        assert_rel(a, b, 2e-5, "gradients vs the fp32 kernel")
+    if noise_kind != "tensor" and mip == 0:
+        # the other two training entry points in split mode: targets from a resident image, and an incoming dY (autograd)
+        geo = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                                 split_bf16=True, **kw)
+        g0d, g1d = g0.to(dev).requires_grad_(True), g1.to(dev).requires_grad_(True)
+        pd = [q.clone().requires_grad_(True) for q in params]
+        y = fused.fused_grid_mlp(geo, g0d, g1d, origins, pd)
+        (((y - target.to(dev)) ** 2).mean()).backward()
+        assert_rel(g0d.grad, ref.grad_g0, 1e-4, "autograd (dY entry point) grad G0")
+        assert_rel(pd[0].grad, ref.grad_mlp[0], 1e-4, "autograd (dY entry point) grad W1")
+
+
 def test_baseline_configs_3_to_5_at_reduced_size(dev):
     """BASELINE.json configs beyond the bench workload, as parity cases.  (3) the 33^3 colour LUT: one crop of the whole
     volume on ceil(33/4)+1 = 10 / 6-node grids, the reference's permuted weights and the textbook-trilinear switch.
