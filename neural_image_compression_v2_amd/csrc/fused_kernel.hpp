@@ -103,7 +103,9 @@ struct Lds {
     // PREC_SPLIT: the wave-private region holds bf16 images with the SAMPLE as the row (32 rows), hi and lo of each: DZ (a2, then
     // dZ2, then dZ1: 64 columns), A1 (64 columns), X (KPAD columns), and dZ3 as [4][32].  Every consumer reads them with
     // ds_read_b64_tr_b16 (sizes in bf16 elements).
-    static constexpr int LDZB = kH + 8, LDXB = KPAD + 8;
+    // row strides of 34 / 42 dwords (= 2 mod 4): the fragment stores (32 lanes, 32 rows, one 8-byte chunk) are conflict-free, the
+    // transposed reads 2-way (72 / 88 elements had both 2-way: 39 % of the LDS-active cycles were conflicts)
+    static constexpr int LDZB = kH + 4, LDXB = KPAD + 4;
     static constexpr int BZ = 32 * LDZB, BX = 32 * LDXB;
     static constexpr int SPW = 4 * BZ + 2 * BX + 256;         // per wave
     static constexpr int TOTAL_SPLIT = OFF_SCR + 4 * SPW / 2;
