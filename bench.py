@@ -7,7 +7,9 @@ on BASELINE.json's configs[1]: a 3840 x 2160 RGB fit, dense G0/G1 grid pair (ref
 
 Prints ONE JSON line on rank 0 (see the driver contract); adds `roofline` (dominant kernel = fused_kernel, timed with HIP
 events on its launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded
-strip of the same workload).
+strip of the same workload).  --precision split (default): the 2D training default, every matrix product as hi + lo bf16 pairs on
+the bf16 matrix pipe with fp32 accumulation (gradients within 5e-6 of the fp32 kernel; parity-tested against the CPU oracle at the
+fp32 kernel's tolerances); --precision f32: v_mfma_f32_32x32x2_f32 throughout.
 """
 import argparse
 import ctypes
