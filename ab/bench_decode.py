@@ -22,5 +22,11 @@ def timeit(fn, n=20):
 a = timeit(lambda: fused.fused_forward(geo, fq[0], fq[1], org, params))
 b = timeit(lambda: fused.fused_forward_u8(geo, fu[0], fu[1], org, params))
 c = timeit(lambda: fused.fused_forward_u8(geo, fu[0], fu[1], org, params, out="uint8"))
+gs = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, split_bf16=True)
+a2 = timeit(lambda: fused.fused_forward(gs, fq[0], fq[1], org, params))
+b2 = timeit(lambda: fused.fused_forward_u8(gs, fu[0], fu[1], org, params))
+ya, yb = fused.fused_forward(geo, fq[0], fq[1], org, params), fused.fused_forward(gs, fq[0], fq[1], org, params)
+print(f"split-bf16 decode 4K: fp32 grids {a2*1e3:.3f} ms ({H*W/a2/1e6:.0f} Mpix/s) | uint8 grids {b2*1e3:.3f} ms ({H*W/b2/1e6:.0f} Mpix/s); max |y_split - y_f32| = {float((ya - yb).abs().max()):.2e}, "
+      f"bytes differing: {int((torch.floor(ya * 255 + 0.5) != torch.floor(yb * 255 + 0.5)).sum())} of {ya.numel()}")
 print(f"decode 4K: fp32 grids {a*1e3:.3f} ms ({H*W/a/1e6:.0f} Mpix/s) | uint8 grids {b*1e3:.3f} ms ({H*W/b/1e6:.0f} Mpix/s) | uint8 grids -> bytes {c*1e3:.3f} ms ({H*W/c/1e6:.0f} Mpix/s)")
 assert torch.equal(fused.fused_forward(geo, fq[0], fq[1], org, params), fused.fused_forward_u8(geo, fu[0], fu[1], org, params))

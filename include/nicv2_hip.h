@@ -91,8 +91,9 @@ typedef struct nic_path_desc {
  * runs on the bf16 matrix pipe with each fp32 operand carried as a hi + lo bf16 pair (16 significant bits, three bf16 MFMAs
  * per product, fp32 accumulation).  Activations, noise, loss, the 3-output layer and all accumulators stay fp32.  Agreement
  * with the fp32 kernels: outputs ~3e-7, gradients <= 5e-6 relative (the fp32 kernels themselves sit at ~1e-6 from the CPU
- * oracle), at 1.7x the speed - the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.  Inference entry
- * points ignore the flag; 3D layouts return NIC_E_UNSUPPORTED. */
+ * oracle), at 1.7x the speed - the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.  The 2D inference
+ * entry points (nic_fused_forward, nic_fused_forward_u8) honour it too (outputs within 3e-7, 2x faster); 3D layouts run their
+ * fp32 kernels for inference and return NIC_E_UNSUPPORTED for training. */
 #define NIC_FLAG_SPLIT_BF16 2
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */

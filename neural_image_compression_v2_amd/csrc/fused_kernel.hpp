@@ -634,9 +634,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     constexpr bool TRAIN = MODE != MODE_INFER;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : Lds<L>::KT;     // dX row tiles: the grid slots / every slot
-    static_assert(!SPLIT || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE && TRAIN), "split-bf16: training from the grids, k-steps of 8 slots");
+    static_assert(!SPLIT || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE), "split-bf16: kernels that encode from the grids, k-steps of 8 slots");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
-    static_assert(!SPLIT || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 layout is built for the 2D slot layouts");
+    static_assert(!SPLIT || !TRAIN || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 training layout is built for the 2D slot layouts");
     __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : S::TOTAL_INFER];
     lds_f* const sm = (lds_f*)smem;
     lds_f* const W1s = sm + S::OFF_W1;

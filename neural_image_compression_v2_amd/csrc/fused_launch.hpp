@@ -27,7 +27,13 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
         using L = Layout<METHOD>;                                                                                        \
         const dim3 g(grid), b(256);                                                                                      \
         if (src == SRC_ENCODE) {                                                                                         \
-            if (mode == MODE_INFER && p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t>), g, b, 0, s, p); \
+            if (mode == MODE_INFER && (p.d.flags & NIC_FLAG_SPLIT_BF16) && L::NSLOT % 8 == 0 && L::DIM == 2) {         \
+                if constexpr (L::NSLOT % 8 == 0 && L::DIM == 2) {                                                        \
+                    if (p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t, PREC_SPLIT>), g, b, 0, s, p); \
+                    else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, float, PREC_SPLIT>), g, b, 0, s, p); \
+                }                                                                                                        \
+            }                                                                                                            \
+            else if (mode == MODE_INFER && p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t>), g, b, 0, s, p); \
             else if (p.grid_u8) return NIC_E_UNSUPPORTED;                                                               \
             else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER>), g, b, 0, s, p);   \
             else if (p.d.flags & NIC_FLAG_SPLIT_BF16) {                          /* training kernels, 2D layouts */      \

@@ -262,14 +262,15 @@ class ImageCompression:
             stored = fp[2 * fl].dtype == torch.uint8
             run = (lambda geo, org: fused.fused_forward_u8(geo, fp[2 * fl], fp[2 * fl + 1], org, params)) if stored else \
                   (lambda geo, org: fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], org, params))
+            split = bool(c.TF_SPLIT_BF16) and D == 2          # the 2D kernels' split-bf16 products (2 x faster, outputs within 3e-7)
             if div_slice == 1:
-                y = run(self._geometry(fl, mip_level, decode_size, 1), [[0] * D])
+                y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split), [[0] * D])
                 return y.reshape(*([decode_size] * D), 3)
             if D != 2:
                 raise NotImplementedError("tiled decode is 2D only, like the reference (image_compression.py:329-345)")
             s = decode_size // div_slice
             result = torch.zeros(decode_size, decode_size, 3, dtype=torch.float32, device=self.device)
-            geo = self._geometry(fl, mip_level, s, 1)
+            geo = self._geometry(fl, mip_level, s, 1, split_bf16=split)
             for i in range(div_slice * div_slice):
                 tx, ty = i % div_slice, i // div_slice
                 result[s * tx:s * (tx + 1), s * ty:s * (ty + 1), :] = run(geo, [[s * tx, s * ty]]).reshape(s, s, 3)

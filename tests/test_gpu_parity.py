@@ -609,7 +609,7 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
     from neural_image_compression_v2_amd.var2 import Settings
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     g = np.load(os.path.join(gdir, "stored_decode.npz"))
-    ic = ImageCompression(Settings(IMAGE_SIZE=64, CROP_MIP_LEVEL=6), device=dev, seed=0)
+    ic = ImageCompression(Settings(IMAGE_SIZE=64, CROP_MIP_LEVEL=6, TF_SPLIT_BF16=False), device=dev, seed=0)   # fp32 products: bit-level claims
     stored = ic.load_compressed(os.path.join(gdir, "stored_feature_pyramid.pth"), os.path.join(gdir, "stored_decoder.pth"))
     assert all(t.dtype == torch.uint8 and t.is_cuda for t in stored)
     y_u8path = ic.decode_image(stored, ic.decoder, 0)
@@ -622,6 +622,13 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
     assert_exact(yf.reshape(64, 64, 3), y_u8path)
     assert_exact(yq.to(torch.float32), torch.round(models.quantize_to_bit(yf, 8)), "byte output")
     assert np.array_equal(yq.reshape(64, 64, 3).cpu().numpy(), np.rint(g["y_to_bit"]).astype(np.uint8))
+    # (a') the same decode with the split-bf16 products (the 2D default): same tolerance against the reference, a handful of bytes at most
+    ic2 = ImageCompression(Settings(IMAGE_SIZE=64, CROP_MIP_LEVEL=6), device=dev, seed=0)
+    stored2 = ic2.load_compressed(os.path.join(gdir, "stored_feature_pyramid.pth"), os.path.join(gdir, "stored_decoder.pth"))
+    y_split = ic2.decode_image(stored2, ic2.decoder, 0)
+    assert_rel(y_split, g["y"], 2e-6, "split-bf16 decode of the reference's stored files")
+    assert_exact(y_split, ic2.decode_image(fp_def.fp_load(stored2, 8, torch.float32), ic2.decoder, 0), "split: uint8-grid decode vs fp_load decode")
+    assert int((torch.round(models.quantize_to_bit(y_split, 8)).cpu() != torch.from_numpy(np.rint(g["y_to_bit"]))).sum()) <= 2
     # (b) 3D, both methods, off-origin tiles
     gen = torch.Generator().manual_seed(11)
     from neural_image_compression_v2_amd.image_compression import ColorDecoder
