@@ -108,7 +108,10 @@ struct Lds {
     static constexpr int LDZB = kH + 4, LDXB = KPAD + 4;
     static constexpr int BZ = 32 * LDZB, BX = 32 * LDXB;
     static constexpr int SPW = 4 * BZ + 2 * BX + 256;         // per wave
-    static constexpr int TOTAL_SPLIT = OFF_SCR + 4 * SPW / 2;
+    static constexpr int W3B = 2 * 16 * LD2;                  // W3 as a bf16 image, hi + lo: 16 rows (3 real), LD2 elements per row
+    static constexpr int OFF_IMG = OFF_SCR + W3B / 2;         // (floats) the wave images start behind it
+    static constexpr int TOTAL_INFER_SPLIT = OFF_IMG;
+    static constexpr int TOTAL_SPLIT = OFF_IMG + 4 * SPW / 2;
     static_assert(SPW % 8 == 0, "16-byte aligned wave regions");
 };
 
@@ -633,11 +636,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     using S = Lds<L>;
     constexpr bool TRAIN = MODE != MODE_INFER;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
+    constexpr bool L3MM = SPLIT && MODE != MODE_INFER;      // layer 3 on the matrix pipe: pays where the a2 fragments exist anyway (training)
     constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : Lds<L>::KT;     // dX row tiles: the grid slots / every slot
     static_assert(!SPLIT || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE), "split-bf16: kernels that encode from the grids, k-steps of 8 slots");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
     static_assert(!SPLIT || !TRAIN || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 training layout is built for the 2D slot layouts");
-    __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : S::TOTAL_INFER];
+    __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : (SPLIT ? S::TOTAL_INFER_SPLIT : S::TOTAL_INFER)];
     lds_f* const sm = (lds_f*)smem;
     lds_f* const W1s = sm + S::OFF_W1;
     lds_f* const W2s = sm + S::OFF_W2;
@@ -684,10 +688,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         const int o = idx / LD2, k = idx - o * LD2;
         W3s[idx] = (o < 3 && k < kH) ? p.W[2][o * kH + k] : 0.f;
     }
+    lds_bf* const W3b = (lds_bf*)(sm + S::OFF_SCR);            // SPLIT only
+    if (SPLIT) {
+        for (int idx = tid; idx < 16 * LD2; idx += 256) {
+            const int c = idx / LD2, k = idx - c * LD2;
+            const float v = (c < 3 && k < kH) ? p.W[2][c * kH + k] : 0.f;
+            const __bf16 hi = (__bf16)v;
+            W3b[idx] = hi;
+            W3b[16 * LD2 + idx] = (__bf16)(v - (float)hi);
+        }
+    }
     if (tid < kH) B2s[tid] = p.b[1][tid];
     if (tid < 16) B3s[tid] = tid < 3 ? p.b[2][tid] : 0.f;
     if (TRAIN)
-        for (int idx = tid; idx < (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) - S::OFF_SCR; idx += 256) smem[S::OFF_SCR + idx] = 0.f;
+        for (int idx = tid + (SPLIT ? S::OFF_IMG : S::OFF_SCR); idx < (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN); idx += 256) smem[idx] = 0.f;
     __syncthreads();
     lds_f* const SCR0 = sm + S::OFF_SCR;                        // wave 0's scratch; wave w's is SCR_PER_WAVE * w further
 
@@ -793,7 +807,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         lds_bf* dz_st = nullptr, *a1_st = nullptr, *x_st = nullptr, *d3_st = nullptr;
         lds_cbf* dz_tr = nullptr, *a1_tr = nullptr, *x_tr = nullptr, *dz_p16 = nullptr, *x_p16 = nullptr, *dz_b44 = nullptr, *d3_a44 = nullptr;
         if constexpr (SPLIT && TRAIN) {
-            lds_bf* const img0 = (lds_bf*)(sm + S::OFF_SCR);
+            lds_bf* const img0 = (lds_bf*)(sm + S::OFF_IMG);
             lds_bf* const imgw = img0 + wave * S::SPW;
             const int q4 = (lane & 15) >> 2, p4 = lane & 3, cg = (lane >> 4) & 1, g16 = lane >> 4;
             dz_st = (lds_bf*)opaque((lds_cbf*)(imgw + pl * S::LDZB + 4 * h));
@@ -808,7 +822,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             dz_b44 = opaque((lds_cbf*)(imgw + q4 * S::LDZB + 16 * g16 + 4 * p4));
             d3_a44 = opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + (lane & 3) * 32));
         }
+        lds_cbf* w3b_row = nullptr, *w3b_tr = nullptr;
         if constexpr (SPLIT) {
+            w3b_row = opaque((lds_cbf*)W3b + (pl & 15) * LD2 + 4 * h);            // rows 16 .. 31 of the A operand re-read rows 0 .. 15
+            w3b_tr = opaque((lds_cbf*)W3b + (4 * h + ((lane & 15) >> 2)) * LD2 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
             w1b_row = opaque((lds_cbf*)W1b + pl * LD1 + 4 * h);
             w2b_row = opaque((lds_cbf*)W2b + pl * LD2 + 4 * h);
             w1b_tr = opaque((lds_cbf*)W1b + (4 * h + ((lane & 15) >> 2)) * LD1 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
@@ -997,8 +1014,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 w3q[3];
+                    if (!L3MM) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) w3q[c] = ld4(&w3_row[c * LD2 + 32 * to + 8 * r4]);
+                        for (int c = 0; c < 3; ++c) w3q[c] = ld4(&w3_row[c * LD2 + 32 * to + 8 * r4]);
+                    }
                     const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
                     f32x4_t aq4, dq4;
                     gelu_and_grad4(zq, aq4, dq4);
@@ -1006,16 +1025,39 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     for (int j = 0; j < 4; ++j) {
                         a2[to][4 * r4 + j] = aq4[j];
                         d2[to][4 * r4 + j] = TRAIN ? dq4[j] : 0.f;
+                        if (!L3MM) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) part3[c] = fmaf(w3q[c][j], aq4[j], part3[c]);
+                            for (int c = 0; c < 3; ++c) part3[c] = fmaf(w3q[c][j], aq4[j], part3[c]);
+                        }
                     }
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(1);    // X^T store, layers 1 + 2 (MFMA), their GELUs, layer 3's dot products
         float yv[3];
+        if constexpr (L3MM) {
+            // layer 3 as one more chained split product: A = the W3 image (16 rows, 3 real; the other row tile re-reads them),
+            // B = the a2 fragments - which are also the a2 image of dW3.  Rows 0..2 of the result sit in registers 0..2 of the
+            // lane that owns the sample (lane half 0).
+            f32x16 z3 = f32x16(0.f);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(part3[c] + __shfl_xor(part3[c], 32) + B3s[c]);
+            for (int ks = 0; ks < 4; ++ks) {
+                const Frag2 bf = split_acc(a2[ks >> 1], ks & 1);
+                if (TRAIN) {                                             // the DZ region is free until dZ2 is stored
+                    store_frag(&dz_st[16 * ks], bf.hi);
+                    store_frag(&dz_st[S::BZ + 16 * ks], bf.lo);
+                }
+                Frag2 af;
+                af.hi = frag_row(&w3b_row[16 * ks]);
+                af.lo = frag_row(&w3b_row[16 * LD2 + 16 * ks]);
+                z3 = mfma_split(af, bf, z3);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + B3s[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(part3[c] + __shfl_xor(part3[c], 32) + B3s[c]);
+        }
+        STAMP(1);    // X^T store, layers 1 + 2 (MFMA), their GELUs, layer 3
         if (p.y != nullptr && valid && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
@@ -1047,13 +1089,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         if constexpr (SPLIT && SRC == SRC_ENCODE) {
         // ================= split-bf16 backward: every product on the bf16 matrix pipe, operands from the [sample][feature] images
-        // ---------- a2 -> the DZ region (free until dZ2 is stored), dZ3 -> its [c][s] image
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const Frag2 f = split_acc(a2[ks >> 1], ks & 1);
-            store_frag(&dz_st[16 * ks], f.hi);
-            store_frag(&dz_st[S::BZ + 16 * ks], f.lo);
-        }
+        // ---------- (the a2 image was stored with layer 3) dZ3 -> its [c][s] image
         if (h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1073,21 +1109,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             accW3q = mfma4_bf(ah, bl, accW3q);
             accW3q = mfma4_bf(ah, bh, accW3q);
         }
-        // ---------- dA2 = W3^T dZ3 (K = 3, padded to 4; fp32 MFMA), dZ2 = dA2 * gelu'(Z2)
+        // ---------- dA2 = W3^T dZ3: one k-step (rows c = 0..2 of 16; lane half 0 carries dZ3 in elements 0..2), dZ2 = dA2 * gelu'(Z2)
         f32x16 dz2[2];
         {
-            const float s1 = __shfl(dz3[1], pl);
-            const float b0 = h ? s1 : dz3[0];
-            const float b1 = h ? 0.f : dz3[2];
+            const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};      // lane half 1: zeros (dZ3 is masked there)
+            const Frag2 bf = split8(dzv);
 #pragma unroll
             for (int tk = 0; tk < 2; ++tk) {
-                f32x16 acc = f32x16(0.f);
-                acc = mfma32(w3_col[32 * tk], b0, acc);
-                acc = mfma32(w3_col[2 * LD2 + 32 * tk], b1, acc);
-                dz2[tk] = acc * d2[tk];
+                Frag2 af;
+                af.hi = frag_tr<LD2>(&w3b_tr[32 * tk]);
+                af.lo = frag_tr<LD2>(&w3b_tr[16 * LD2 + 32 * tk]);
+                dz2[tk] = mfma_split(af, bf, f32x16(0.f)) * d2[tk];
             }
         }
-        STAMP(2);    // a2 / dZ3 images, dW3, dA2
+        STAMP(2);    // dZ3 image, dW3, dA2
         wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
         // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are also the dZ2 image of the weight-gradient product
         f32x16 dz1[2];
