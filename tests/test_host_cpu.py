@@ -80,6 +80,47 @@ def test_path_desc_layout_matches_the_c_header():
         assert getattr(NicTargetImage, f).offset == off, f
 
 
+def test_argument_errors_are_reported_before_any_gpu_work(lib):
+    """error convention of the C ABI (include/nicv2_hip.h): negative NIC_E_* codes for bad arguments, decided on the host - no
+    device is needed (and none is touched) to get them"""
+    from neural_image_compression_v2_amd import _lib
+    E_NULL, E_UNSUPPORTED, E_SHAPE, E_WORKSPACE, E_ARG = -1, -2, -3, -4, -5
+    d = _lib.NicPathDesc()
+    d.dim, d.method, d.channels, d.pe_channels, d.hidden = 2, 1, 12, 6, 64
+    d.num_crops = 1
+    for a in range(3):
+        d.extent[a], d.g0_nodes[a], d.g1_nodes[a] = 8, 17, 9
+    null = ctypes.c_void_p(0)
+    fake = ctypes.c_void_p(16)                              # never dereferenced: the checks fail first
+    m = _lib.NicMlp()
+    assert lib.nic_fused_forward(None, fake, fake, fake, ctypes.byref(m), null, fake, null) == E_NULL
+    assert lib.nic_fused_forward(ctypes.byref(d), null, fake, fake, ctypes.byref(m), null, fake, null) == E_NULL
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_NULL     # empty nic_mlp
+    d.channels = 5
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_UNSUPPORTED
+    d.channels, d.dim, d.method = 12, 3, 1
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_UNSUPPORTED
+    d.dim, d.method, d.num_crops = 2, 1, 0
+    for i in range(3):
+        m.w[i] = m.b[i] = 16
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_SHAPE
+    d.num_crops, d.log2_step = 1, 40
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_ARG
+    d.log2_step = -2
+    gs = _lib.NicMlpGrads()
+    assert lib.nic_fused_forward_backward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null, fake, fake, fake,
+                                          ctypes.byref(gs), fake, 16, null) == E_WORKSPACE
+    d.noise_mode = _lib.NIC_NOISE_KERNEL
+    assert lib.nic_fused_forward_u8(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), fake, null, null) == E_ARG    # decoding adds no noise
+    assert lib.nic_adam_multi(None, 3, 0.9, 0.999, 1e-8, null) == E_NULL
+    arr = (_lib.NicAdamTensor * 1)()
+    assert lib.nic_adam_multi(arr, 33, 0.9, 0.999, 1e-8, null) == E_ARG
+    assert lib.nic_adam_multi(arr, 0, 0.9, 0.999, 1e-8, null) == 0
+    assert lib.nic_quantize(null, fake, 4, 8, null) == E_NULL
+    assert lib.nic_load4fp_u8(fake, fake, 4, 9, null) == E_ARG
+    assert b"unsupported" in lib.nic_error_string(E_UNSUPPORTED).lower() or len(lib.nic_error_string(E_UNSUPPORTED)) > 0
+
+
 def test_no_cpu_path():
     """every product entry point refuses CPU tensors instead of computing something else"""
     from neural_image_compression_v2_amd import fp_def, fused, models, utils
