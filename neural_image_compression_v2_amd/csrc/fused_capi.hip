@@ -63,6 +63,19 @@ int check_geometry(const nic_path_desc* d) {
 }
 
 // persistent grid: a multiple of 8 blocks (one slice of the tile range per XCD), at most `per_cu` per CU
+// Small launches: when the macro-tiles do not fill the persistent grid at least twice, deal their rounds out in 2 or 4 groups
+// (a macro-tile of the default 8 x 256^2 step is 16 rounds of ~25K cycles; 1 320 of them on 1 024 waves left a third of the
+// waves idle for the second half: 0.41 -> 0.36 ms per step with 2 groups).  Each group flushes its own grid-gradient sums,
+// so more groups than the balance needs cost time (4 groups: 0.41 ms again).
+#ifndef NIC_RG_MAX
+#define NIC_RG_MAX 2
+#endif
+void balance_units(FusedParams& p, int per_cu) {
+    const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * 4;
+    p.rg_log2 = 0;
+    while (p.rg_log2 < NIC_RG_MAX && (p.niter >> (p.rg_log2 + 1)) >= 1 && (p.n_tiles << p.rg_log2) < 2 * waves) ++p.rg_log2;
+}
+
 int grid_for(int64_t n_tiles, int per_cu) {
     int64_t want = (n_tiles + 3) / 4;                 // 4 waves per block, one tile each
     want = (want + 7) / 8 * 8;
@@ -99,6 +112,7 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.tiles_y = ty; p.tiles_z = tz;
     p.tiles_per_crop = (int64_t)tx * ty * tz;
     p.n_tiles = p.tiles_per_crop * d->num_crops;
+    p.rg_log2 = 0;
     p.noise.mode = d->noise_mode;
     p.noise.tensor = noise;
     p.noise.k0 = (uint32_t)d->noise_seed; p.noise.k1 = (uint32_t)(d->noise_seed >> 32);
@@ -155,7 +169,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_rcp = 1.0f / p.timg_den;
     }
     p.partials = (float*)workspace;
-    const int grid = grid_for(p.n_tiles, 1);
+    balance_units(p, 1);
+    const int grid = grid_for(p.n_tiles << p.rg_log2, 1);
     const int n_rec = grid * 4 / fi.waves_per_rec;
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -193,7 +208,8 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     fill_encode(p, d, fi, g0, g1, origins, noise);
     fill_mlp(p, mlp);
     p.y = y;
-    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
+    balance_units(p, 2);
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2), (hipStream_t)stream);
 }
 
 int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uint8_t* g1_u8, const int32_t* origins, const nic_mlp* mlp,
@@ -214,7 +230,8 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     p.dq_den = (float)((1 << d->num_bits) - 1);
     p.dq_rcp = 1.0f / p.dq_den;
     p.y = y; p.y_u8 = y_u8;
-    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles, 2), (hipStream_t)stream);
+    balance_units(p, 2);
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2), (hipStream_t)stream);
 }
 
 int nic_fused_forward_backward(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,

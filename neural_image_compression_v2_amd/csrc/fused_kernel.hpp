@@ -62,6 +62,7 @@ struct FusedParams {
     int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;
     int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile
+    int rg_log2;           // the rounds of a macro-tile are dealt out in 2^rg_log2 groups (work units): small launches balance better
     float grad_scale;      // 2 * loss_scale
 };
 
@@ -728,9 +729,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 
     // ---------------- XCD-aware persistent walk, in workgroup-synchronous rounds of 4 tiles (one per wave)
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
-    const int64_t chunk = (p.n_tiles + 7) >> 3;
+    // work unit = (macro-tile, group of rounds); units of one macro-tile are consecutive, so they land on the waves of one workgroup
+    const int64_t n_units = p.n_tiles << p.rg_log2;
+    const int64_t chunk = (n_units + 7) >> 3;
     const int64_t t_begin = xcd * chunk;
-    const int64_t t_end = t_begin + chunk < p.n_tiles ? t_begin + chunk : p.n_tiles;
+    const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
     const int lstride = nb8 * 4;
 
 #ifdef NIC_STAMPS
@@ -744,7 +747,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
         // last tile with every lane masked, which contributes exact zeros everywhere
         const bool tile_ok = base + wave < t_end;
-        const int64_t tile = tile_ok ? base + wave : t_end - 1;
+        const int64_t unit = tile_ok ? base + wave : t_end - 1;
+        const int64_t tile = unit >> p.rg_log2;
+        const int it_len = (SRC == SRC_ENCODE ? p.niter : 1) >> p.rg_log2, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * it_len;
         // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
         int crop = 0;
         int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
@@ -781,7 +786,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
 
         STAMP(12);   // macro-tile setup
-      for (int it = 0; it < (SRC == SRC_ENCODE ? p.niter : 1); ++it) {          // one sample of the cell block per round
+      for (int it = it_begin; it < it_begin + it_len; ++it) {                   // one sample of the cell block per round
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         // ---------- per-lane LDS bases (every access below is base[compile-time constant])
         lds_cf* const w1_row = opaque(W1s + pl * LD1 + 4 * h);      // A rows of layer 1 (b128 along k)
