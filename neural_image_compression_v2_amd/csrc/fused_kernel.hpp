@@ -1,29 +1,32 @@
-// Fused encode + decoder MLP forward / backward for gfx950 (CDNA4), fp32 in / fp32 accumulate on the
-// exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+// Fused encode + decoder MLP forward / backward for gfx950 (CDNA4): fused_kernel<Layout, SRC, MODE, GT, PREC>.
 //
-// Work decomposition
-//   * one wave = one tile of 32 samples at a time; a 256-thread workgroup is 4 independent waves that
-//     only share the decoder weights in LDS (no workgroup barrier inside the tile loop);
-//   * persistent grid (<= 1 workgroup per CU for training: the wave keeps every decoder-gradient
-//     accumulator tile in its accumulator registers for the whole launch), XCD-aware tile order:
-//     blocks b and b+8 share an XCD / L2, so each XCD walks one contiguous range of tiles and
-//     neighbouring tiles re-use the same grid cells out of that XCD's L2;
-//   * sample-on-lane orientation: every activation matrix is [features, 32 samples] with the sample
-//     on the MFMA column (lane & 31).  A 32x32 accumulator register r of lane-half h then holds
-//     feature row ROW(r,h) of the lane's own sample, which is precisely the B operand the next
-//     layer's MFMA wants (k-step = register index): the three forward layers and the two backward
-//     dA products chain through registers with no LDS traffic.  Only the weight-gradient products,
-//     which contract over the sample index, go through a transposed wave-private LDS image.
-//   * lanes map to grid CELLS, not to consecutive samples: a wave owns a 16 x 2 (x 1 in 3D) block of G0 cells, lanes x-fastest, and
-//     walks the m^D samples inside a cell (m = 1/step_number: 16 rounds at mip 0) one per round.  All samples of a
-//     lane share their G0 corners and their G1 cell, so the input gradient - which leaves the last backward product in
-//     the registers of the lane that knows the slot's grid address - is summed in registers over the rounds and
-//     scattered ONCE per cell with fp32 atomics (the reference's index_put_(accumulate=True),
-//     image_compression.py:265): 16x fewer atomics, no lanes of one instruction on the same address, and no
-//     cross-lane reduction.  (Per-sample atomics ran at the contended memory-side rate; LDS float atomics at about
-//     one lane per clock - both measured and dropped, see DESIGN.md.)
-//   * decoder-gradient accumulators are written once per wave to a workspace and summed in a fixed
-//     order by reduce_partials_kernel (bit-stable decoder gradients and loss).
+//   SRC   SRC_ENCODE: the input rows are built from the grids in-kernel (gathers, blend, PE, noise);  SRC_MEMORY: read from [N, Cin]
+//   MODE  MODE_INFER | MODE_TRAIN_MSE (target tensor) | MODE_TRAIN_IMG (target read from the resident image) | MODE_TRAIN_DY (incoming dY)
+//   GT    grid element type: float, or uint8_t = the stored codec, dequantised in the gather (inference)
+//   PREC  PREC_F32: every matrix product on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain);
+//         PREC_SPLIT (2D): every matrix product on the bf16 matrix pipe with hi + lo bf16 operand pairs and fp32 accumulation -
+//         see "split-bf16 matrix products" below; the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.
+//
+// Work decomposition (both precisions)
+//   * one wave = one tile of 32 samples at a time; a 256-thread workgroup is 4 waves that share the decoder weights in LDS and,
+//     in training, split the ownership of the weight-gradient tiles (4 LDS barriers per round);
+//   * persistent grid (<= 1 workgroup per CU for training: a wave keeps the decoder-gradient accumulator tiles it owns in
+//     registers for the whole launch), XCD-aware work order: blocks b and b+8 share an XCD / L2, so each XCD walks one
+//     contiguous range of work units and neighbouring units re-use the same grid cells out of that XCD's L2;
+//   * sample-on-lane orientation: every activation matrix is [features, 32 samples] with the sample on the MFMA column
+//     (lane & 31).  A 32x32 accumulator register r of lane-half h then holds feature row ROW(r,h) of the lane's own sample,
+//     which is precisely the B operand the next product wants: the forward layers and the backward dA products chain
+//     through registers with no LDS traffic.  Only the weight-gradient products, which contract over the sample index, go
+//     through wave-private LDS images ([feature][sample] fp32, or [sample][feature] bf16 read with ds_read_b64_tr_b16);
+//   * lanes map to grid CELLS, not to consecutive samples: a wave owns a 16 x 2 (x 1 in 3D) block of G0 cells, lanes x-fastest,
+//     and walks the m^D samples inside a cell (m = 1/step_number: 16 rounds at mip 0) one per round.  All samples of a lane
+//     share their G0 corners and their G1 cell, so the input gradient - which leaves the last backward product in the
+//     registers of the lane that knows the slot's grid address - is summed in registers over the rounds and scattered ONCE
+//     per cell with fp32 atomics (the reference's index_put_(accumulate=True), image_compression.py:265), the G1 sums of the
+//     lanes that share a G1 cell combined across lanes first.  (Per-sample atomics ran at the contended memory-side rate;
+//     LDS float atomics at about one lane per clock - both measured and dropped, see DESIGN.md.)
+//   * decoder-gradient accumulators are written once per workgroup to a workspace and summed in a fixed order by
+//     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
 #ifndef NIC_HOIST_TRAIN
