@@ -199,6 +199,11 @@ __device__ __forceinline__ void store_frag(lds_bf* p, const bf16x8& f) {        
 __device__ __forceinline__ s16x4 tr4(lds_cbf* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p); }
 __device__ __forceinline__ f32x4 mfma16_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4_bf(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
+// the same for the [sample][feature] images: base row r and r + 1, each read combining rows +0, +8, +16, +24 (set up in p)
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_trs(lds_cbf* p) {
+    return join8(tr4(p), tr4(p + LD));
+}
 // acc += A (hi, lo) x B (hi, lo) without the lo x lo term (2^-18 relative)
 __device__ __forceinline__ f32x16 mfma_split(const Frag2& a, const Frag2& b, f32x16 c) {
     c = mfma_bf(a.lo, b.hi, c);
@@ -821,13 +826,17 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             dz_st = (lds_bf*)opaque((lds_cbf*)(imgw + pl * S::LDZB + 4 * h));
             a1_st = dz_st + 2 * S::BZ;
             x_st = (lds_bf*)opaque((lds_cbf*)(imgw + 4 * S::BZ + pl * S::LDXB + 4 * h));
-            d3_st = (lds_bf*)opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + pl));
-            dz_tr = opaque((lds_cbf*)(img0 + (4 * h + q4) * S::LDZB + 16 * cg + 4 * p4));
+            // Which 4 samples a transposed read combines is free (A and B operands use the same rule): rows r, r + 8, r + 16,
+            // r + 24 sit 16 bank pairs apart under the 34 / 42-dword strides, so the reads are conflict-free (4 consecutive rows
+            // were 2-way).  The 8 base rows r of a wave's 32 samples: 32x32x16: r = 4 (k-step) + 2 (lane half) + (read 0 / 1);
+            // 16x16x32: r = 2 (lane >> 4) + read; 4x4x4: r = MFMA index (the dZ3 image is stored in that order: [c][4 r + q]).
+            d3_st = (lds_bf*)opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + 4 * (pl & 7) + (pl >> 3)));
+            dz_tr = opaque((lds_cbf*)(img0 + (8 * q4 + 2 * h) * S::LDZB + 16 * cg + 4 * p4));
             a1_tr = dz_tr + 2 * S::BZ;
-            x_tr = opaque((lds_cbf*)(img0 + 4 * S::BZ + (4 * h + q4) * S::LDXB + 16 * cg + 4 * p4));
-            dz_p16 = opaque((lds_cbf*)(imgw + (8 * g16 + q4) * S::LDZB + 4 * p4));
-            x_p16 = opaque((lds_cbf*)(imgw + 4 * S::BZ + (8 * g16 + q4) * S::LDXB + 32 * (KT - 1) + 4 * p4));
-            dz_b44 = opaque((lds_cbf*)(imgw + q4 * S::LDZB + 16 * g16 + 4 * p4));
+            x_tr = opaque((lds_cbf*)(img0 + 4 * S::BZ + (8 * q4 + 2 * h) * S::LDXB + 16 * cg + 4 * p4));
+            dz_p16 = opaque((lds_cbf*)(imgw + (8 * q4 + 2 * g16) * S::LDZB + 4 * p4));
+            x_p16 = opaque((lds_cbf*)(imgw + 4 * S::BZ + (8 * q4 + 2 * g16) * S::LDXB + 32 * (KT - 1) + 4 * p4));
+            dz_b44 = opaque((lds_cbf*)(imgw + 8 * q4 * S::LDZB + 16 * g16 + 4 * p4));
             d3_a44 = opaque((lds_cbf*)(imgw + 4 * S::BZ + 2 * S::BX + (lane & 3) * 32));
         }
         lds_cbf* w3b_row = nullptr, *w3b_tr = nullptr;
@@ -1110,9 +1119,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- dW3[c][k = lane] += sum_s dZ3[c][s] A2[k][s]: 4x4x4 MFMAs (16 blocks of 4 columns: lane l <-> column l),
         // A = dZ3[c = lane & 3][4 samples] (the same in every block), B = column l of 4 sample rows of the a2 image
 #pragma unroll
-        for (int s0 = 0; s0 < 32; s0 += 4) {
-            const s16x4 bh = tr4(&dz_b44[s0 * S::LDZB]), bl = tr4(&dz_b44[S::BZ + s0 * S::LDZB]);
-            const s16x4 ah = *reinterpret_cast<lds_cs16x4*>(&d3_a44[s0]), al = *reinterpret_cast<lds_cs16x4*>(&d3_a44[128 + s0]);
+        for (int r = 0; r < 8; ++r) {                                  // samples r, r + 8, r + 16, r + 24
+            const s16x4 bh = tr4(&dz_b44[r * S::LDZB]), bl = tr4(&dz_b44[S::BZ + r * S::LDZB]);
+            const s16x4 ah = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]), al = *reinterpret_cast<lds_cs16x4*>(&d3_a44[128 + 4 * r]);
             accW3q = mfma4_bf(al, bh, accW3q);
             accW3q = mfma4_bf(ah, bl, accW3q);
             accW3q = mfma4_bf(ah, bh, accW3q);
@@ -1157,9 +1166,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         {
             const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
 #pragma unroll
-            for (int s0 = 0; s0 < 32; s0 += 4) {
-                accB2q = mfma4_bf(ones, tr4(&dz_b44[S::BZ + s0 * S::LDZB]), accB2q);
-                accB2q = mfma4_bf(ones, tr4(&dz_b44[s0 * S::LDZB]), accB2q);
+            for (int r = 0; r < 8; ++r) {
+                accB2q = mfma4_bf(ones, tr4(&dz_b44[S::BZ + r * S::LDZB]), accB2q);
+                accB2q = mfma4_bf(ones, tr4(&dz_b44[r * S::LDZB]), accB2q);
             }
         }
         STAMP(3);    // dA1 (+ dZ2 image), db2
@@ -1168,12 +1177,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- dW2 tile (to2, tk2) += sum over the four waves' samples of dZ2[o][s] A1[k][s]
 #pragma unroll
         for (int ksw = 0; ksw < 8; ++ksw) {                            // k-step = (source wave, 16 samples)
-            const int off = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDZB;
+            const int off = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB;
             Frag2 af, bf;
-            af.hi = frag_tr<S::LDZB>(&dz_tr[off + 32 * to2]);
-            af.lo = frag_tr<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
-            bf.hi = frag_tr<S::LDZB>(&a1_tr[off + 32 * tk2]);
-            bf.lo = frag_tr<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
+            af.hi = frag_trs<S::LDZB>(&dz_tr[off + 32 * to2]);
+            af.lo = frag_trs<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
+            bf.hi = frag_trs<S::LDZB>(&a1_tr[off + 32 * tk2]);
+            bf.lo = frag_trs<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
             accW2o = mfma_split(af, bf, accW2o);
         }
         STAMP(5);    // dW2 MFMAs (owned tile, 4 sources)
@@ -1207,18 +1216,18 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         for (int c2 = 0; c2 < NCH; ++c2) {
 #pragma unroll
             for (int ksw = 0; ksw < 8; ++ksw) {
-                const int offz = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDZB, offx = (ksw >> 1) * S::SPW + 16 * (ksw & 1) * S::LDXB;
+                const int offz = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB, offx = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDXB;
                 Frag2 af, bf;
-                af.hi = frag_tr<S::LDZB>(&dz_tr[offz + 32 * to1]);
-                af.lo = frag_tr<S::LDZB>(&dz_tr[offz + S::BZ + 32 * to1]);
-                bf.hi = frag_tr<S::LDXB>(&x_tr[offx + 64 * c2 + 32 * tk1]);
-                bf.lo = frag_tr<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
+                af.hi = frag_trs<S::LDZB>(&dz_tr[offz + 32 * to1]);
+                af.lo = frag_trs<S::LDZB>(&dz_tr[offz + S::BZ + 32 * to1]);
+                bf.hi = frag_trs<S::LDXB>(&x_tr[offx + 64 * c2 + 32 * tk1]);
+                bf.lo = frag_trs<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
                 accW1o[c2] = mfma_split(af, bf, accW1o[c2]);
             }
         }
         // odd last col tile (16 real rows): 16x16x32 over this wave's own 32 samples, 4 row tiles of 16
         {
-            auto frag16 = [&](lds_cbf* ptr, int ld) { return join8(tr4(ptr), tr4(ptr + 4 * ld)); };
+            auto frag16 = [&](lds_cbf* ptr, int ld) { return join8(tr4(ptr), tr4(ptr + ld)); };
             Frag2 bf;
             bf.hi = frag16(&x_p16[0], S::LDXB);
             bf.lo = frag16(&x_p16[S::BX], S::LDXB);
