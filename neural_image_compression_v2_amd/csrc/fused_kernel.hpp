@@ -29,6 +29,9 @@
 //     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
+#ifndef NIC_HOIST_INFER
+#define NIC_HOIST_INFER -1  // inference: -1 = by layout (4-corner G0 layouts: both grids; 3D method 3: G0 only - 96 raw values per lane spill at 2 waves per SIMD)
+#endif
 #ifndef NIC_HOIST_TRAIN
 #define NIC_HOIST_TRAIN 0   // bit 0: G0, bit 1: G1 raw values gathered once per macro-tile in the training kernels
 #endif
@@ -783,8 +786,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         GridAcc<L> gacc;
         uint32_t blk_off0 = 0, blk_off1 = 0;
         // which raw grid values are gathered once per macro-tile: inference has the registers for both grids
-        constexpr bool HG0 = SRC == SRC_ENCODE && (TRAIN ? (NIC_HOIST_TRAIN & 1) != 0 : true);
-        constexpr bool HG1 = SRC == SRC_ENCODE && (TRAIN ? (NIC_HOIST_TRAIN & 2) != 0 : true);
+        constexpr int HOIST_INFER = NIC_HOIST_INFER >= 0 ? NIC_HOIST_INFER : (L::K0 == 4 ? 3 : 1);   // measured per layout
+        constexpr bool HG0 = SRC == SRC_ENCODE && ((TRAIN ? NIC_HOIST_TRAIN : HOIST_INFER) & 1) != 0;
+        constexpr bool HG1 = SRC == SRC_ENCODE && ((TRAIN ? NIC_HOIST_TRAIN : HOIST_INFER) & 2) != 0;
         CellRaw<L> raw;
         if (SRC == SRC_ENCODE && (TRAIN || HG0 || HG1)) {
             const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};

@@ -27,8 +27,8 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
         using L = Layout<METHOD>;                                                                                        \
         const dim3 g(grid), b(256);                                                                                      \
         if (src == SRC_ENCODE) {                                                                                         \
-            if (mode == MODE_INFER && (p.d.flags & NIC_FLAG_SPLIT_BF16) && L::NSLOT % 8 == 0 && L::DIM == 2) {         \
-                if constexpr (L::NSLOT % 8 == 0 && L::DIM == 2) {                                                        \
+            if (mode == MODE_INFER && (p.d.flags & NIC_FLAG_SPLIT_BF16) && L::NSLOT % 8 == 0) {   /* 2D and 3D method 3 */ \
+                if constexpr (L::NSLOT % 8 == 0) {                                                                       \
                     if (p.grid_u8) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, uint8_t, PREC_SPLIT>), g, b, 0, s, p); \
                     else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_INFER, float, PREC_SPLIT>), g, b, 0, s, p); \
                 }                                                                                                        \

@@ -639,6 +639,11 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
         a = fused.fused_forward_u8(geo3, u0, u1, org, dec.linear_params())
         b = fused.fused_forward(geo3, models.load4fp(u0, 8, torch.float32), models.load4fp(u1, 8, torch.float32), org, dec.linear_params())
         assert_exact(a, b, f"3D method {method}")
+        if method == 3:
+            u0m3, u1m3, dec3, b3 = u0, u1, dec, b
+    # (b') 3D method 3 inference in split-bf16 (the 3D training kernels are fp32 only)
+    geo3s = fused.PathGeometry(3, 3, 0.25, 0, (12, 9, 16), 1, split_bf16=True)
+    assert_rel(fused.fused_forward_u8(geo3s, u0m3, u1m3, [[4, 8, 16]], dec3.linear_params()), b3, 2e-6, "3D method 3 split-bf16 decode")
     # (d) round trip through the container
     fp32 = [torch.rand(12, 17, 17, device=dev) - 0.5, torch.rand(12, 9, 9, device=dev) - 0.5]
     f1, f2 = str(tmp_path / "fp.pth"), str(tmp_path / "dec.pth")
