@@ -23,8 +23,6 @@ for method, cin in ((3, 127), (4, 79)):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"3D method {method}: {S}^3 voxels fwd+bwd {dt*1e3:.2f} ms -> {S**3/dt/1e6:.1f} Mvox/s, loss {float(out.loss):.5f}")
     for split in (False, True):
-        if split and method == 4:
-            continue
         gd = fused.PathGeometry(dim=3, method=method, step_number=0.25, mip_level=0, extent=(S, S, S), num_crops=1, split_bf16=split)
         for i in range(3): fused.fused_forward(gd, fp[0].detach(), fp[1].detach(), org, params)
         torch.cuda.synchronize(); t0 = time.perf_counter()

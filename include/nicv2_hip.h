@@ -92,8 +92,8 @@ typedef struct nic_path_desc {
  * per product, fp32 accumulation).  Activations, noise, loss, the 3-output layer and all accumulators stay fp32.  Agreement
  * with the fp32 kernels: outputs ~3e-7, gradients <= 5e-6 relative (the fp32 kernels themselves sit at ~1e-6 from the CPU
  * oracle), at 1.7x the speed - the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.  The 2D inference
- * entry points (nic_fused_forward, nic_fused_forward_u8) honour it too (outputs within 3e-7, 2x faster), and so does 3D method 3
- * inference; 3D method 4 inference runs its fp32 kernel, 3D training returns NIC_E_UNSUPPORTED. */
+ * entry points (nic_fused_forward, nic_fused_forward_u8) honour it too, 2D and 3D (outputs within 3e-7, 1.6-2x faster); 3D training
+ * returns NIC_E_UNSUPPORTED (the split images of the 3D layouts do not fit the LDS). */
 #define NIC_FLAG_SPLIT_BF16 2
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */

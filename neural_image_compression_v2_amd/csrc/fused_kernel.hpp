@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         GridAcc<L> gacc;
         uint32_t blk_off0 = 0, blk_off1 = 0;
         // which raw grid values are gathered once per macro-tile: inference has the registers for both grids
-        constexpr int HOIST_INFER = NIC_HOIST_INFER >= 0 ? NIC_HOIST_INFER : (L::K0 == 4 ? 3 : 1);   // measured per layout
+        constexpr int HOIST_INFER = NIC_HOIST_INFER >= 0 ? NIC_HOIST_INFER : (L::DIM == 2 ? 3 : (SPLIT ? 1 : (L::K0 == 4 ? 3 : 1)));   // measured per layout
         constexpr bool HG0 = SRC == SRC_ENCODE && ((TRAIN ? NIC_HOIST_TRAIN : HOIST_INFER) & 1) != 0;
         constexpr bool HG1 = SRC == SRC_ENCODE && ((TRAIN ? NIC_HOIST_TRAIN : HOIST_INFER) & 2) != 0;
         CellRaw<L> raw;

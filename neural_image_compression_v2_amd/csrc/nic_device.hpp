@@ -298,7 +298,7 @@ template <>
 struct Layout<4> {
     static constexpr int DIM = 3, K0 = 4, K1 = 8, CIN = 79;
     static constexpr int PE = NIC_PE_SINUSOIDAL;        // fp_def.py:208
-    static constexpr int NSLOT = 44;   // 16 + 16 + 12 -> KPAD = 88
+    static constexpr int NSLOT = 48;   // 16 + 16 + 16 -> KPAD = 96 (42 real slots; a multiple of 8 so that split-bf16 k-steps cover whole slots)
     static constexpr int NGRID = 30;
     static constexpr int TX = 16, TY = 2, TZ = 1;   // x-fastest like 2D (the 2 x 4 x 4 block touched 16 grid rows per gather: -10 %)
     __host__ __device__ static constexpr int slot_channel(int s, int h) {

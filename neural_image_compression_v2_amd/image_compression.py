@@ -262,7 +262,7 @@ class ImageCompression:
             stored = fp[2 * fl].dtype == torch.uint8
             run = (lambda geo, org: fused.fused_forward_u8(geo, fp[2 * fl], fp[2 * fl + 1], org, params)) if stored else \
                   (lambda geo, org: fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], org, params))
-            split = bool(c.TF_SPLIT_BF16) and (D == 2 or c.COMPRESSION_METHOD == 3)   # split-bf16 products (2 x faster, outputs within 3e-7)
+            split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)
             if div_slice == 1:
                 y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split), [[0] * D])
                 return y.reshape(*([decode_size] * D), 3)

@@ -629,6 +629,7 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
     # (b) 3D, both methods, off-origin tiles
     gen = torch.Generator().manual_seed(11)
     from neural_image_compression_v2_amd.image_compression import ColorDecoder
+    split3d = {}
     for method, cin in ((3, 127), (4, 79)):
         u0 = torch.randint(0, 256, (12, 9, 9, 9), generator=gen, dtype=torch.uint8).to(dev)
         u1 = torch.randint(0, 256, (12, 5, 5, 5), generator=gen, dtype=torch.uint8).to(dev)
@@ -639,11 +640,11 @@ def test_decode_from_stored_uint8_grids(dev, tmp_path):
         a = fused.fused_forward_u8(geo3, u0, u1, org, dec.linear_params())
         b = fused.fused_forward(geo3, models.load4fp(u0, 8, torch.float32), models.load4fp(u1, 8, torch.float32), org, dec.linear_params())
         assert_exact(a, b, f"3D method {method}")
-        if method == 3:
-            u0m3, u1m3, dec3, b3 = u0, u1, dec, b
-    # (b') 3D method 3 inference in split-bf16 (the 3D training kernels are fp32 only)
-    geo3s = fused.PathGeometry(3, 3, 0.25, 0, (12, 9, 16), 1, split_bf16=True)
-    assert_rel(fused.fused_forward_u8(geo3s, u0m3, u1m3, [[4, 8, 16]], dec3.linear_params()), b3, 2e-6, "3D method 3 split-bf16 decode")
+        split3d[method] = (u0, u1, dec, b)
+    # (b') 3D inference in split-bf16, both methods (the 3D training kernels are fp32 only)
+    for method, (u0_, u1_, dec_, b_) in split3d.items():
+        geo3s = fused.PathGeometry(3, method, 0.25, 0, (12, 9, 16), 1, split_bf16=True)
+        assert_rel(fused.fused_forward_u8(geo3s, u0_, u1_, [[4, 8, 16]], dec_.linear_params()), b_, 2e-6, f"3D method {method} split-bf16 decode")
     # (d) round trip through the container
     fp32 = [torch.rand(12, 17, 17, device=dev) - 0.5, torch.rand(12, 9, 9, device=dev) - 0.5]
     f1, f2 = str(tmp_path / "fp.pth"), str(tmp_path / "dec.pth")
