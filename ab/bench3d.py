@@ -13,9 +13,10 @@ for method, cin in ((3, 127), (4, 79)):
     params = [p.detach() for p in dec.linear_params()]
     target = torch.rand(S ** 3, 3, device=dev)
     org = [[0, 0, 0]]                                        # host origins: the wrapper sees they are cell-aligned
+    SPLIT_TRAIN = os.environ.get("SPLIT3D", "1") == "1"
     def step(i):
         geo = fused.PathGeometry(dim=3, method=method, step_number=0.25, mip_level=0, extent=(S, S, S), num_crops=1,
-                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i)
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, split_bf16=SPLIT_TRAIN)
         return fused.fused_forward_backward(geo, fp[0].detach(), fp[1].detach(), org, params, target)
     for i in range(3): step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()

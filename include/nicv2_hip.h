@@ -87,13 +87,14 @@ typedef struct nic_path_desc {
  * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1
  * (origins live on the device, the library cannot look). Setting it for unaligned origins drops samples. */
 #define NIC_FLAG_ORIGINS_ALIGNED 1
-/* Training entry points (nic_fused_forward_backward, _img, nic_fused_backward_dy), 2D only: every matrix product of the step
- * runs on the bf16 matrix pipe with each fp32 operand carried as a hi + lo bf16 pair (16 significant bits, three bf16 MFMAs
- * per product, fp32 accumulation).  Activations, noise, loss, the 3-output layer and all accumulators stay fp32.  Agreement
- * with the fp32 kernels: outputs ~3e-7, gradients <= 5e-6 relative (the fp32 kernels themselves sit at ~1e-6 from the CPU
- * oracle), at 1.7x the speed - the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.  The 2D inference
- * entry points (nic_fused_forward, nic_fused_forward_u8) honour it too, 2D and 3D (outputs within 3e-7, 1.6-2x faster); 3D training
- * returns NIC_E_UNSUPPORTED (the split images of the 3D layouts do not fit the LDS). */
+/* Matrix products on the bf16 matrix pipe with each fp32 operand carried as a hi + lo bf16 pair (16 significant bits, three
+ * bf16 MFMAs per product, fp32 accumulation); activations, noise, loss and all accumulators stay fp32.
+ *   2D training (nic_fused_forward_backward, _img, nic_fused_backward_dy): every product of the step, 1.8x faster;
+ *   3D training: the four chained products (layer 1, layer 2 and their input-gradient transposes), 1.2x faster - the
+ *     [sample][feature] bf16 images of the weight-gradient products do not fit the LDS next to the 3D weights;
+ *   inference (nic_fused_forward, nic_fused_forward_u8), every layout: layers 1 and 2, 1.6-2x faster.
+ * Agreement with the fp32 kernels: outputs ~3e-7, gradients <= 7e-6 relative (the fp32 kernels themselves sit ~1e-6 from the
+ * CPU oracle).  The fp32-input MFMA blocks the wave's vector issue, the bf16 one does not. */
 #define NIC_FLAG_SPLIT_BF16 2
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */

@@ -136,7 +136,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // of a tile, converted pairwise, are the B fragment of k-step s (element j of lane half g = row 16s + 8(j>>2) + 4g + (j&3));
 // the A fragment of a natural [row][k] bf16 image is two 8-byte reads at k = 16s + 4g and + 8 (row-wise), or two
 // ds_read_b64_tr_b16 of the 4 x 16 blocks at rows 16s + 4g and + 8 (the transposed product), from ONE image.
-enum { PREC_F32 = 0, PREC_SPLIT = 1 };
+// PREC_CHAIN: only the four chained products (layer 1, layer 2, dA1, dX) in split bf16; the weight-gradient products, layer 3 and
+// dA2 stay fp32 on the fp32 [feature][sample] images - for the 3D training kernels, whose split images do not fit the LDS
+enum { PREC_F32 = 0, PREC_SPLIT = 1, PREC_CHAIN = 2 };
 // between the k-steps of a split product the scheduler is left free: the next step's operand split (VALU) and LDS reads run
 // beside the current step's bf16 MFMAs (3.51 -> 3.42 ms against a scheduling barrier per step)
 #ifndef NIC_SPLIT_SB
@@ -648,9 +650,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     using S = Lds<L>;
     constexpr bool TRAIN = MODE != MODE_INFER;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
+    constexpr bool CHAIN = PREC != PREC_F32;                // bf16 weight images + split chained products
     constexpr bool L3MM = SPLIT && MODE != MODE_INFER;      // layer 3 on the matrix pipe: pays where the a2 fragments exist anyway (training)
     constexpr int NGT = SRC == SRC_ENCODE ? (L::NGRID + 15) / 16 : Lds<L>::KT;     // dX row tiles: the grid slots / every slot
-    static_assert(!SPLIT || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE), "split-bf16: kernels that encode from the grids, k-steps of 8 slots");
+    static_assert(!CHAIN || (L::NSLOT % 8 == 0 && SRC == SRC_ENCODE), "split-bf16: kernels that encode from the grids, k-steps of 8 slots");
+    static_assert(PREC != PREC_CHAIN || TRAIN, "PREC_CHAIN is a training mode");
     constexpr int KT = S::KT, LD1 = S::LD1, LD2 = S::LD2, LDT = S::LDT;
     static_assert(!SPLIT || !TRAIN || (S::TOTAL_SPLIT * 4 <= 163840 && S::PART16), "split-bf16 training layout is built for the 2D slot layouts");
     __shared__ __attribute__((aligned(16))) float smem[TRAIN ? (SPLIT ? S::TOTAL_SPLIT : S::TOTAL_TRAIN) : (SPLIT ? S::TOTAL_INFER_SPLIT : S::TOTAL_INFER)];
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             if (ch >= 0) v = p.W[0][o * L::CIN + ch];
             else if (ch == kSlotOne) v = p.b[0][o];
         }
-        if (SPLIT) {
+        if (CHAIN) {
             const __bf16 hi = (__bf16)v;
             W1b[idx] = hi;
             W1b[kH * LD1 + idx] = (__bf16)(v - (float)hi);
@@ -688,7 +692,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     for (int idx = tid; idx < kH * LD2; idx += 256) {
         const int o = idx / LD2, k = idx - o * LD2;
         const float v = k < kH ? p.W[1][o * kH + k] : 0.f;
-        if (SPLIT) {
+        if (CHAIN) {
             const __bf16 hi = (__bf16)v;
             W2b[idx] = hi;
             W2b[kH * LD2 + idx] = (__bf16)(v - (float)hi);
@@ -847,6 +851,8 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         if constexpr (SPLIT) {
             w3b_row = opaque((lds_cbf*)W3b + (pl & 15) * LD2 + 4 * h);            // rows 16 .. 31 of the A operand re-read rows 0 .. 15
             w3b_tr = opaque((lds_cbf*)W3b + (4 * h + ((lane & 15) >> 2)) * LD2 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+        }
+        if constexpr (CHAIN) {
             w1b_row = opaque((lds_cbf*)W1b + pl * LD1 + 4 * h);
             w2b_row = opaque((lds_cbf*)W2b + pl * LD2 + 4 * h);
             w1b_tr = opaque((lds_cbf*)W1b + (4 * h + ((lane & 15) >> 2)) * LD1 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
@@ -927,13 +933,13 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 a1[2], d1[2];
         {
             f32x16 z[2] = {f32x16(0.f), f32x16(0.f)};
-            if constexpr (SPLIT) {
+            if constexpr (CHAIN) {
                 // k-step b = slots 8b .. 8b+7 of both lane halves = internal rows 16b + 8(j>>2) + 4g + (j&3)
 #pragma unroll
                 for (int b = 0; b < L::NSLOT / 8; ++b) {
                     const float xv[8] = {xs[8 * b], xs[8 * b + 1], xs[8 * b + 2], xs[8 * b + 3], xs[8 * b + 4], xs[8 * b + 5], xs[8 * b + 6], xs[8 * b + 7]};
                     const Frag2 bf = split8(xv);
-                    if (TRAIN) {                                         // the X image of the weight-gradient product: columns 16b + 4h.. and + 8
+                    if (TRAIN && SPLIT) {                                // the X image of the weight-gradient product: columns 16b + 4h.. and + 8
                         store_frag(&x_st[16 * b], bf.hi);
                         store_frag(&x_st[S::BX + 16 * b], bf.lo);
                     }
@@ -997,11 +1003,11 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[to][4 * r4 + j] = bb[j];
                 }
-            if constexpr (SPLIT) {
+            if constexpr (CHAIN) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {                         // k-step (t, s): hidden rows 32t + 16s + ..
                     const Frag2 bf = split_acc(a1[ks >> 1], ks & 1);
-                    if (TRAIN) {
+                    if (TRAIN && SPLIT) {
                         store_frag(&a1_st[16 * ks], bf.hi);
                         store_frag(&a1_st[S::BZ + 16 * ks], bf.lo);
                     }
@@ -1341,7 +1347,19 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         f32x16 dz1[2];
         {
             f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
-            {
+            if constexpr (CHAIN) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                         // contraction rows o = 16 ks + ..
+                    const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tk = 0; tk < 2; ++tk) {
+                        Frag2 af;
+                        af.hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
+                        af.lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
+                        acc[tk] = mfma_split(af, bf, acc[tk]);
+                    }
+                }
+            } else {
             // A operands (columns of W2) are fetched one step (2 k-steps = 4 MFMAs) ahead: the LDS latency of step i + 1
             // runs under the MFMAs of step i instead of in front of them
             float wq[2][4];
@@ -1490,7 +1508,19 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 dxacc[NGT];
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
-            {
+            if constexpr (CHAIN) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tg = 0; tg < NGT; ++tg) {
+                        Frag2 af;
+                        af.hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
+                        af.lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
+                        dxacc[tg] = mfma_split(af, bf, dxacc[tg]);
+                    }
+                }
+            } else {
             // same one-step-ahead operand fetch as dA1
             float wq[2][2 * NGT];
 #pragma unroll

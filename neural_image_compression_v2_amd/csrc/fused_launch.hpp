@@ -41,6 +41,10 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
                     if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_SPLIT>), g, b, 0, s, p); \
                     else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_IMG, float, PREC_SPLIT>), g, b, 0, s, p); \
                     else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY, float, PREC_SPLIT>), g, b, 0, s, p); \
+                } else if constexpr (L::NSLOT % 8 == 0) {     /* 3D: chained products only (PREC_CHAIN) */              \
+                    if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_CHAIN>), g, b, 0, s, p); \
+                    else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_IMG, float, PREC_CHAIN>), g, b, 0, s, p); \
+                    else hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_DY, float, PREC_CHAIN>), g, b, 0, s, p); \
                 } else return NIC_E_UNSUPPORTED;                                                                        \
             }                                                                                                            \
             else if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_kernel<L, SRC_ENCODE, MODE_TRAIN_MSE>), g, b, 0, s, p); \

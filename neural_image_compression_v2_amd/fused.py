@@ -119,7 +119,7 @@ class PathGeometry:
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
-        if self.split_bf16 or (os.environ.get("NIC_FORCE_SPLIT_BF16") == "1" and self.dim == 2):   # env: test switch for the whole suite
+        if self.split_bf16 or os.environ.get("NIC_FORCE_SPLIT_BF16") == "1":   # env: test switch for the whole suite
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         return d
 

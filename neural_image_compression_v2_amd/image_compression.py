@@ -180,7 +180,7 @@ class ImageCompression:
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
-                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16) and D == 2)
+                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16))
             out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target)
             self.optimizer.zero_grad(set_to_none=True)
             fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1

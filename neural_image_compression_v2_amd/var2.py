@@ -39,8 +39,9 @@ class Settings:
     INTERVAL_SAVE_MODEL: int = 100000
     TF_NO_MIP: bool = True
     TF_USE_TRI_PE: bool = True
-    TF_SPLIT_BF16: bool = True           # not in the reference: 2D fused training steps run their matrix products as hi + lo bf16 pairs on
-                                         # the bf16 matrix pipe (1.7x; gradients within 5e-6 of the fp32 kernel).  False: fp32 MFMAs throughout
+    TF_SPLIT_BF16: bool = True           # not in the reference: fused training steps and decodes run their matrix products as hi + lo bf16
+                                         # pairs on the bf16 matrix pipe (2D: all of them, 1.8x; 3D: the chained ones, 1.2x; gradients within
+                                         # 5e-6 of the fp32 kernels).  False: fp32 MFMAs throughout
     TF_TRAIN_MODEL: bool = True
     TF_SHOW_RESULT: bool = False
     TF_PRINT_LOG: bool = True

@@ -275,11 +275,11 @@ def test_fused_forward_backward_matches_oracle(dev, case):
         assert torch.equal(a, b), "decoder gradients are bit-stable run to run"
 
 
-@pytest.mark.parametrize("case", [c for c in FUSED_CASES if c[0] == 2], ids=lambda c: f"split-{c[3]}-{'x'.join(map(str, c[4]))}-{c[6]}".replace(" ", ""))
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: f"split-d{c[0]}m{c[1]}-{c[3]}-{'x'.join(map(str, c[4]))}-{c[6]}".replace(" ", ""))
 def test_split_bf16_training_step(dev, case):
-    """NIC_FLAG_SPLIT_BF16 (every matrix product of the 2D training step as hi + lo bf16 pairs on the bf16 matrix pipe) against
-    the CPU oracle at the SAME tolerances as the fp32 kernel, and against the fp32 kernel itself (outputs 2e-6, gradients 2e-5);
-    all three training entry points (MSE on a target tensor, MSE on the resident image, incoming dY)."""
+    """NIC_FLAG_SPLIT_BF16 (2D: every matrix product of the training step as hi + lo bf16 pairs on the bf16 matrix pipe; 3D: the four
+    chained products) against the CPU oracle at the SAME tolerances as the fp32 kernel, and against the fp32 kernel itself (outputs
+    2e-6, gradients 2e-5); all three training entry points (MSE on a target tensor, MSE on the resident image, incoming dY)."""
     from neural_image_compression_v2_amd import _lib, fused
     dim, method, tri, base, extent, origins, noise_kind = case
     fl, mip = 0, 0
@@ -289,22 +289,23 @@ def test_split_bf16_training_step(dev, case):
     g0, g1 = fp[2 * fl], fp[2 * fl + 1]
     step = O.step_number_of(mip, fl)
     g = torch.Generator().manual_seed(78)
-    mlp = O.init_mlp(73, 64, generator=g)
+    cin = O.decoder_input_channels(12, 6, dim, method)
+    mlp = O.init_mlp(cin, 64, generator=g)
     n = len(origins) * int(np.prod(extent))
     target = torch.rand(n, 3, generator=g)
     noise, kw = None, {}
     if noise_kind == "tensor":
-        noise = (torch.rand(n, 73, generator=g) - 0.5) / 256
+        noise = (torch.rand(n, cin, generator=g) - 0.5) / 256
         kw = dict(noise_mode=_lib.NIC_NOISE_TENSOR)
     elif noise_kind == "kernel":
-        noise = O.kernel_noise(n, 73, 8, seed=5, offset=6)
+        noise = O.kernel_noise(n, cin, 8, seed=5, offset=6)
         kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5, noise_offset=6)
-    ref = O.forward_backward(g0, g1, mlp, origins, extent, step, mip, target, noise, 6, method=1, use_tri_pe=tri)
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, step, mip, target, noise, 6, method=method, use_tri_pe=tri)
     params = [q.to(dev) for q in mlp.tensors()]
     nd = noise.to(dev) if noise_kind == "tensor" else None
     outs = {}
     for split in (False, True):
-        geo = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
                                  split_bf16=split, **kw)
         outs[split] = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd, want_y=True)
     out, f32 = outs[True], outs[False]
@@ -319,7 +320,7 @@ def test_split_bf16_training_step(dev, case):
         assert_rel(a, b, 2e-5, "gradients vs the fp32 kernel")
     if noise_kind != "tensor" and mip == 0:
         # the other two training entry points in split mode: targets from a resident image, and an incoming dY (autograd)
-        geo = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
                                  split_bf16=True, **kw)
         g0d, g1d = g0.to(dev).requires_grad_(True), g1.to(dev).requires_grad_(True)
         pd = [q.clone().requires_grad_(True) for q in params]
