@@ -141,6 +141,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 enum { PREC_F32 = 0, PREC_SPLIT = 1, PREC_CHAIN = 2 };
 // between the k-steps of a split product the scheduler is left free: the next step's operand split (VALU) and LDS reads run
 // beside the current step's bf16 MFMAs (3.51 -> 3.42 ms against a scheduling barrier per step)
+#ifndef NIC_DW_SB
+#define NIC_DW_SB __builtin_amdgcn_sched_barrier(0)   // keeps the one-step-ahead order of the weight-gradient loops
+#endif
 #ifndef NIC_SPLIT_SB
 #define NIC_SPLIT_SB ((void)0)
 #endif
@@ -1185,15 +1188,22 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         wg_lds_barrier();
         STAMP(4);    // wait at barrier 1
         // ---------- dW2 tile (to2, tk2) += sum over the four waves' samples of dZ2[o][s] A1[k][s]
+        {
+            auto load2 = [&](int ksw, Frag2& af, Frag2& bf) {             // k-step = (source wave, 16 samples)
+                const int off = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB;
+                af.hi = frag_trs<S::LDZB>(&dz_tr[off + 32 * to2]);
+                af.lo = frag_trs<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
+                bf.hi = frag_trs<S::LDZB>(&a1_tr[off + 32 * tk2]);
+                bf.lo = frag_trs<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
+            };
+            Frag2 af[2], bf[2];                                            // fragments of step k + 1 are in flight during step k
+            load2(0, af[0], bf[0]);
 #pragma unroll
-        for (int ksw = 0; ksw < 8; ++ksw) {                            // k-step = (source wave, 16 samples)
-            const int off = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB;
-            Frag2 af, bf;
-            af.hi = frag_trs<S::LDZB>(&dz_tr[off + 32 * to2]);
-            af.lo = frag_trs<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
-            bf.hi = frag_trs<S::LDZB>(&a1_tr[off + 32 * tk2]);
-            bf.lo = frag_trs<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
-            accW2o = mfma_split(af, bf, accW2o);
+            for (int ksw = 0; ksw < 8; ++ksw) {
+                if (ksw + 1 < 8) load2(ksw + 1, af[(ksw + 1) & 1], bf[(ksw + 1) & 1]);
+                accW2o = mfma_split(af[ksw & 1], bf[ksw & 1], accW2o);
+                NIC_DW_SB;
+            }
         }
         STAMP(5);    // dW2 MFMAs (owned tile, 4 sources)
         wg_lds_barrier();                                              // everyone is done reading dZ2 before dZ1 replaces it
@@ -1224,15 +1234,20 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- dW1 tiles (to1, 2c + tk1) += sum over the four waves' samples of dZ1[o][s] X[rho][s]
 #pragma unroll
         for (int c2 = 0; c2 < NCH; ++c2) {
-#pragma unroll
-            for (int ksw = 0; ksw < 8; ++ksw) {
+            auto load1 = [&](int ksw, Frag2& af, Frag2& bf) {
                 const int offz = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB, offx = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDXB;
-                Frag2 af, bf;
                 af.hi = frag_trs<S::LDZB>(&dz_tr[offz + 32 * to1]);
                 af.lo = frag_trs<S::LDZB>(&dz_tr[offz + S::BZ + 32 * to1]);
                 bf.hi = frag_trs<S::LDXB>(&x_tr[offx + 64 * c2 + 32 * tk1]);
                 bf.lo = frag_trs<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
-                accW1o[c2] = mfma_split(af, bf, accW1o[c2]);
+            };
+            Frag2 af[2], bf[2];
+            load1(0, af[0], bf[0]);
+#pragma unroll
+            for (int ksw = 0; ksw < 8; ++ksw) {
+                if (ksw + 1 < 8) load1(ksw + 1, af[(ksw + 1) & 1], bf[(ksw + 1) & 1]);
+                accW1o[c2] = mfma_split(af[ksw & 1], bf[ksw & 1], accW1o[c2]);
+                NIC_DW_SB;
             }
         }
         // odd last col tile (16 real rows): 16x16x32 over this wave's own 32 samples, 4 row tiles of 16
