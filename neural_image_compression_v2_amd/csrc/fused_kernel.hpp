@@ -938,8 +938,18 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 z[2] = {f32x16(0.f), f32x16(0.f)};
             if constexpr (CHAIN) {
                 // k-step b = slots 8b .. 8b+7 of both lane halves = internal rows 16b + 8(j>>2) + 4g + (j&3)
+                auto loadw = [&](int b, Frag2 (&af)[2]) {
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        af[to].hi = frag_row(&w1b_row[32 * to * LD1 + 16 * b]);
+                        af[to].lo = frag_row(&w1b_row[kH * LD1 + 32 * to * LD1 + 16 * b]);
+                    }
+                };
+                Frag2 afq[2][2];                                           // weight fragments of step b + 1 in flight during step b
+                loadw(0, afq[0]);
 #pragma unroll
                 for (int b = 0; b < L::NSLOT / 8; ++b) {
+                    if (b + 1 < L::NSLOT / 8) loadw(b + 1, afq[(b + 1) & 1]);
                     const float xv[8] = {xs[8 * b], xs[8 * b + 1], xs[8 * b + 2], xs[8 * b + 3], xs[8 * b + 4], xs[8 * b + 5], xs[8 * b + 6], xs[8 * b + 7]};
                     const Frag2 bf = split8(xv);
                     if (TRAIN && SPLIT) {                                // the X image of the weight-gradient product: columns 16b + 4h.. and + 8
@@ -947,12 +957,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                         store_frag(&x_st[S::BX + 16 * b], bf.lo);
                     }
 #pragma unroll
-                    for (int to = 0; to < 2; ++to) {
-                        Frag2 af;
-                        af.hi = frag_row(&w1b_row[32 * to * LD1 + 16 * b]);
-                        af.lo = frag_row(&w1b_row[kH * LD1 + 32 * to * LD1 + 16 * b]);
-                        z[to] = mfma_split(af, bf, z[to]);
-                    }
+                    for (int to = 0; to < 2; ++to) z[to] = mfma_split(afq[b & 1][to], bf, z[to]);
                     NIC_SPLIT_SB;
                 }
             } else {
@@ -1007,20 +1012,25 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     for (int j = 0; j < 4; ++j) z[to][4 * r4 + j] = bb[j];
                 }
             if constexpr (CHAIN) {
+                auto loadw = [&](int ks, Frag2 (&af)[2]) {
+#pragma unroll
+                    for (int to = 0; to < 2; ++to) {
+                        af[to].hi = frag_row(&w2b_row[32 * to * LD2 + 16 * ks]);
+                        af[to].lo = frag_row(&w2b_row[kH * LD2 + 32 * to * LD2 + 16 * ks]);
+                    }
+                };
+                Frag2 afq[2][2];
+                loadw(0, afq[0]);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {                         // k-step (t, s): hidden rows 32t + 16s + ..
+                    if (ks + 1 < 4) loadw(ks + 1, afq[(ks + 1) & 1]);
                     const Frag2 bf = split_acc(a1[ks >> 1], ks & 1);
                     if (TRAIN && SPLIT) {
                         store_frag(&a1_st[16 * ks], bf.hi);
                         store_frag(&a1_st[S::BZ + 16 * ks], bf.lo);
                     }
 #pragma unroll
-                    for (int to = 0; to < 2; ++to) {
-                        Frag2 af;
-                        af.hi = frag_row(&w2b_row[32 * to * LD2 + 16 * ks]);
-                        af.lo = frag_row(&w2b_row[kH * LD2 + 32 * to * LD2 + 16 * ks]);
-                        z[to] = mfma_split(af, bf, z[to]);
-                    }
+                    for (int to = 0; to < 2; ++to) z[to] = mfma_split(afq[ks & 1][to], bf, z[to]);
                     NIC_SPLIT_SB;
                 }
             } else {
@@ -1069,6 +1079,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             // B = the a2 fragments - which are also the a2 image of dW3.  Rows 0..2 of the result sit in registers 0..2 of the
             // lane that owns the sample (lane half 0).
             f32x16 z3 = f32x16(0.f);
+            Frag2 afq[4];                                                  // all four W3 fragments up front (16 registers)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                afq[ks].hi = frag_row(&w3b_row[16 * ks]);
+                afq[ks].lo = frag_row(&w3b_row[16 * LD2 + 16 * ks]);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const Frag2 bf = split_acc(a2[ks >> 1], ks & 1);
@@ -1076,10 +1092,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     store_frag(&dz_st[16 * ks], bf.hi);
                     store_frag(&dz_st[S::BZ + 16 * ks], bf.lo);
                 }
-                Frag2 af;
-                af.hi = frag_row(&w3b_row[16 * ks]);
-                af.lo = frag_row(&w3b_row[16 * LD2 + 16 * ks]);
-                z3 = mfma_split(af, bf, z3);
+                z3 = mfma_split(afq[ks], bf, z3);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + B3s[c]);
@@ -1131,13 +1144,21 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         wave_lds_fence();
         // ---------- dW3[c][k = lane] += sum_s dZ3[c][s] A2[k][s]: 4x4x4 MFMAs (16 blocks of 4 columns: lane l <-> column l),
         // A = dZ3[c = lane & 3][4 samples] (the same in every block), B = column l of 4 sample rows of the a2 image
+        {
+            s16x4 bh[8], bl[8], ah[8], al[8];                              // 32 small reads in flight, then 24 MFMAs
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {                                  // samples r, r + 8, r + 16, r + 24
-            const s16x4 bh = tr4(&dz_b44[r * S::LDZB]), bl = tr4(&dz_b44[S::BZ + r * S::LDZB]);
-            const s16x4 ah = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]), al = *reinterpret_cast<lds_cs16x4*>(&d3_a44[128 + 4 * r]);
-            accW3q = mfma4_bf(al, bh, accW3q);
-            accW3q = mfma4_bf(ah, bl, accW3q);
-            accW3q = mfma4_bf(ah, bh, accW3q);
+            for (int r = 0; r < 8; ++r) {                                  // samples r, r + 8, r + 16, r + 24
+                bh[r] = tr4(&dz_b44[r * S::LDZB]);
+                bl[r] = tr4(&dz_b44[S::BZ + r * S::LDZB]);
+                ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
+                al[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[128 + 4 * r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                accW3q = mfma4_bf(al[r], bh[r], accW3q);
+                accW3q = mfma4_bf(ah[r], bl[r], accW3q);
+                accW3q = mfma4_bf(ah[r], bh[r], accW3q);
+            }
         }
         // ---------- dA2 = W3^T dZ3: one k-step (rows c = 0..2 of 16; lane half 0 carries dZ3 in elements 0..2), dZ2 = dA2 * gelu'(Z2)
         f32x16 dz2[2];
@@ -1184,10 +1205,16 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- db2[o = lane] += sum_s dZ2[o][s]: 4x4x4 MFMAs against a block of ones (every output row is the column sum)
         {
             const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            s16x4 bh[8], bl[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                accB2q = mfma4_bf(ones, tr4(&dz_b44[S::BZ + r * S::LDZB]), accB2q);
-                accB2q = mfma4_bf(ones, tr4(&dz_b44[r * S::LDZB]), accB2q);
+                bl[r] = tr4(&dz_b44[S::BZ + r * S::LDZB]);
+                bh[r] = tr4(&dz_b44[r * S::LDZB]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                accB2q = mfma4_bf(ones, bl[r], accB2q);
+                accB2q = mfma4_bf(ones, bh[r], accB2q);
             }
         }
         STAMP(3);    // dA1 (+ dZ2 image), db2
