@@ -1402,16 +1402,22 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         {
             f32x16 acc[2] = {f32x16(0.f), f32x16(0.f)};
             if constexpr (CHAIN) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {                         // contraction rows o = 16 ks + ..
-                    const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
+                auto loadw = [&](int ks, Frag2 (&af)[2]) {
 #pragma unroll
                     for (int tk = 0; tk < 2; ++tk) {
-                        Frag2 af;
-                        af.hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
-                        af.lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
-                        acc[tk] = mfma_split(af, bf, acc[tk]);
+                        af[tk].hi = frag_tr<LD2>(&w2b_tr[16 * ks * LD2 + 32 * tk]);
+                        af[tk].lo = frag_tr<LD2>(&w2b_tr[kH * LD2 + 16 * ks * LD2 + 32 * tk]);
                     }
+                };
+                Frag2 afq[2][2];
+                loadw(0, afq[0]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                         // contraction rows o = 16 ks + ..
+                    if (ks + 1 < 4) loadw(ks + 1, afq[(ks + 1) & 1]);
+                    const Frag2 bf = split_acc(dz2[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tk = 0; tk < 2; ++tk) acc[tk] = mfma_split(afq[ks & 1][tk], bf, acc[tk]);
+                    NIC_DW_SB;
                 }
             } else {
             // A operands (columns of W2) are fetched one step (2 k-steps = 4 MFMAs) ahead: the LDS latency of step i + 1
@@ -1563,16 +1569,22 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
             if constexpr (CHAIN) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
+                auto loadw = [&](int ks, Frag2 (&af)[NGT]) {
 #pragma unroll
                     for (int tg = 0; tg < NGT; ++tg) {
-                        Frag2 af;
-                        af.hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
-                        af.lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
-                        dxacc[tg] = mfma_split(af, bf, dxacc[tg]);
+                        af[tg].hi = frag_tr<LD1>(&w1b_tr[16 * ks * LD1 + 32 * tg]);
+                        af[tg].lo = frag_tr<LD1>(&w1b_tr[kH * LD1 + 16 * ks * LD1 + 32 * tg]);
                     }
+                };
+                Frag2 afq[2][NGT];
+                loadw(0, afq[0]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) loadw(ks + 1, afq[(ks + 1) & 1]);
+                    const Frag2 bf = split_acc(dz1[ks >> 1], ks & 1);
+#pragma unroll
+                    for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma_split(afq[ks & 1][tg], bf, dxacc[tg]);
+                    NIC_DW_SB;
                 }
             } else {
             // same one-step-ahead operand fetch as dA1
