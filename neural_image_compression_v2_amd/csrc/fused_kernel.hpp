@@ -4,8 +4,9 @@
 //   MODE  MODE_INFER | MODE_TRAIN_MSE (target tensor) | MODE_TRAIN_IMG (target read from the resident image) | MODE_TRAIN_DY (incoming dY)
 //   GT    grid element type: float, or uint8_t = the stored codec, dequantised in the gather (inference)
 //   PREC  PREC_F32: every matrix product on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain);
-//         PREC_SPLIT (2D): every matrix product on the bf16 matrix pipe with hi + lo bf16 operand pairs and fp32 accumulation -
-//         see "split-bf16 matrix products" below; the fp32-input MFMA blocks the wave's vector issue, the bf16 one does not.
+//         PREC_SPLIT (2D training, every layout's inference): every matrix product on the bf16 matrix pipe with hi + lo bf16
+//         operand pairs and fp32 accumulation - see "split-bf16 matrix products" below; the fp32-input MFMA blocks the wave's
+//         vector issue, the bf16 one does not;  PREC_CHAIN (3D training): only the four chained products that way.
 //
 // Work decomposition (both precisions)
 //   * one wave = one tile of 32 samples at a time; a 256-thread workgroup is 4 waves that share the decoder weights in LDS and,
