@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(256) bench(float* out, long long* cyc, int ite
         for (int m = 0; m < 8; ++m) {
             if (MF == 1) acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 1], 0, 0, 0);
             if (MF == 2) acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[m & 1], 0, 0, 0);
+            if (MF == 4) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[0], 0, 0, 0);     // ONE dependent chain
             if (MF == 3) acc4[m & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[m & 1], 0, 0, 0);
             filler<KIND, K>(f, u);
         }
@@ -61,7 +62,7 @@ void run(const char* name, float* out, long long* cyc) {
 }
 #define SWEEP(MF, KIND, name) \
     run<MF, KIND, 0>(name, out, cyc); run<MF, KIND, 4>(name, out, cyc); run<MF, KIND, 8>(name, out, cyc); run<MF, KIND, 12>(name, out, cyc); run<MF, KIND, 16>(name, out, cyc);
-int main() {
+int main(int argc, char**) {
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
     SWEEP(0, 0, "no mfma + v_fma_f32")
@@ -79,5 +80,7 @@ int main() {
     SWEEP(3, 0, "mfma16x16x4f32 + v_fma_f32")
     SWEEP(2, 0, "mfma32x32x16bf16 + v_fma_f32")
     SWEEP(2, 3, "mfma32x32x16bf16 + v_pk_fma_f32")
+    SWEEP(4, 0, "mfma32x32x16bf16 one chain + v_fma")
+    if (argc > 1) return 0;
     return 0;
 }
