@@ -5,6 +5,11 @@ on BASELINE.json's configs[1]: a 3840 x 2160 RGB fit, dense G0/G1 grid pair (ref
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
 
+N > 1 is weak scaling (8.29 Mpx per rank and step).  Default --shard stripes: rank r owns a stripe of the image's second axis (a
+contiguous block of grid node rows) and takes its N passes per step from it - the same sample multiset as N replicas each covering
+the image once, but the step exchanges only the loss, the decoder gradients and one boundary node row per neighbour pair (0.3 MB at
+N = 8) instead of the dense grid gradients (31 MB, --shard replicated); the full grids are assembled once after the timed region.
+
 Prints ONE JSON line on rank 0 (see the driver contract); adds `roofline` (dominant kernel = fused_kernel, timed with HIP
 events on its launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded
 strip of the same workload).  --precision split (default): the 2D training default, every matrix product as hi + lo bf16 pairs on
@@ -84,18 +89,26 @@ def main():
     ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
                     help="tensor: resident fp32 [N,3] targets (the reference's crop stack, built once); image: targets read from the "
                          "resident uint8 image inside the step (a quarter of the bytes, ~3 %% more kernel time: three byte gathers)")
+    ap.add_argument("--shard", choices=["stripes", "replicated"], default="stripes",
+                    help="N > 1.  stripes: every rank owns a stripe of the image's second axis (a contiguous block of grid node rows) and "
+                         "takes its N passes per step from it; the step exchanges the loss, the decoder gradients and one boundary node "
+                         "row per neighbour pair (~0.3 MB) instead of the dense grid gradients.  replicated: every rank covers the whole "
+                         "image once per step and the whole gradient bucket (31 MB) is all-reduced")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NIC_DIST_BACKEND", "nccl")         # "gloo": rehearsal of the N > 1 path on a box with one GPU
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from neural_image_compression_v2_amd import _lib, fp_def, fused
-    from neural_image_compression_v2_amd.distributed import all_reduce_flat
+    from neural_image_compression_v2_amd.distributed import all_reduce_flat, assemble_stripes, plan_stripes, stripe_exchange
     from neural_image_compression_v2_amd.image_compression import ColorDecoder
     lib = _lib.load()
 
@@ -108,9 +121,21 @@ def main():
     if args.target == "image":                                        # 8-bit codes of the same image, resident: u / 255 = img exactly
         target = fused.TargetImage(torch.round(img * 255).to(torch.uint8).to(dev), 255.0)
     n_local = H * W
-    n_global = n_local * world
-    org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
-    offs, sizes, total = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, (H, W), 1), g0, g1)
+    vworld = args.virtual_world if world == 1 and args.virtual_world > 1 else world
+    n_global = n_local * vworld
+    stripes = vworld > 1 and args.shard == "stripes"
+    if stripes:
+        # rank r: the stripe [start, start + size) of image axis 1, `world` passes over it per step (crops at the same origin)
+        plan = plan_stripes(W, 8, rank, vworld)                       # G1 cell = 8 pixels at step 1/4
+        extent, ncrops = (H, plan.size), vworld
+        org = torch.tensor([[0, plan.start]] * vworld, dtype=torch.int32, device=dev)
+        if args.target == "tensor":
+            target = img[:, :, plan.start:plan.start + plan.size].permute(1, 2, 0).reshape(-1, 3).repeat(vworld, 1).contiguous().to(dev)
+    else:
+        extent, ncrops = (H, W), 1
+        org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+    assert extent[0] * extent[1] * ncrops == n_local
+    offs, sizes, total = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, extent, ncrops), g0, g1)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     tensors = params + [g0, g1]                                       # Adam state per tensor, order of the bucket (after the loss)
     m_state = [torch.zeros_like(t) for t in tensors]
@@ -123,13 +148,16 @@ def main():
     adam_tab = (_lib.NicAdamTensor * len(tensors))()
 
     def step(i, events=None):
-        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
                                  sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global),
-                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origin (0, 0)
+                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell
                                  split_bf16=args.precision == "split")
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
-        all_reduce_flat(out.flat)                                     # RCCL sum of [loss | decoder grads | grid grads]
+        if world > 1 and stripes:
+            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)   # RCCL sum of [loss | decoder grads | boundary rows]
+        else:
+            all_reduce_flat(out.flat)                                 # RCCL sum of [loss | decoder grads | grid grads]
         cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))  # CosineAnnealingLR(T_max), eta_min = 0
         grads = out.grad_mlp + [out.grad_g0, out.grad_g1]
         for k, (p, g, m, v) in enumerate(zip(tensors, grads, m_state, v_state)):
@@ -153,22 +181,31 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss = float(out.loss)
+    if world > 1 and stripes:
+        assemble_stripes(plan, g0, g1)                                # once, outside the timed region: the full grids on every rank
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # fused kernel (+ its ~10 us partial reduction)
     # the metric's "+ PSNR" (outside the timed region): decode the whole image with the current parameters, PSNR with peak 2^8
     # against the synthetic target (utils.py:117-130) - after warmup + steps optimiser steps from a random initialisation
     from neural_image_compression_v2_amd import models, utils
     dgeo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
                               flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, split_bf16=args.precision == "split")
-    rec = fused.fused_forward(dgeo, g0, g1, org, params)
+    rec = fused.fused_forward(dgeo, g0, g1, torch.zeros(1, 2, dtype=torch.int32, device=dev), params)
     ref_img = img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(dev)
     psnr = float(utils.calculate_psnr(models.quantize_to_bit(rec, 8), models.quantize_to_bit(ref_img, 8)))
 
     if rank == 0:
-        mpix = n_global * args.steps / elapsed / 1e6
+        mpix = n_local * world * args.steps / elapsed / 1e6
+        if stripes:
+            xb = 4 * (offs[7] + (vworld - 1) * 12 * (g0.shape[2] + g1.shape[2]))
+            par = (f"dp{vworld}, grids sharded in stripes of image axis 1 ({plan.size} px = {vworld} passes per rank and step); exchange per step = "
+                   f"loss + decoder grads + {vworld - 1} boundary node rows of G0 and G1 = {xb} B all-reduced"
+                   + (" (virtual: one process, no collectives)" if world == 1 else ""))
+        else:
+            par = f"dp{world} (sample-sharded, replicated parameters" + (f", {4 * total} B all-reduced per step)" if world > 1 else ")")
         flops = FLOP_PER_SAMPLE * n_local / (kern_ms * 1e-3) / 1e12
         gbs = BYTES_PER_SAMPLE * n_local / (kern_ms * 1e-3) / 1e9
         traffic = None
@@ -186,7 +223,7 @@ def main():
             "config": {"workload": "3840x2160 RGB fit, every pixel once per step: dense G0 [12,961,541] + G1 [12,481,271] grid pair "
                                    "(reference semantics, no-mip), triangular PE, 3xLinear(64) GELU decoder, in-kernel Threefry-4x32-12 noise, MSE, "
                                    "fused fwd+bwd + grad all-reduce + Adam + clamp",
-                       "pixels_per_step_per_gpu": n_local, "parallelism": f"dp{world} (sample-sharded, replicated parameters)",
+                       "pixels_per_step_per_gpu": n_local, "parallelism": par,
                        "final_loss": round(loss, 6), "psnr_db_after_these_steps": round(psnr, 3)},
         }
         common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,

@@ -12,7 +12,7 @@ sharding / bucket / scaling logic is exercised without a GPU.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, replace
+from dataclasses import dataclass, field, replace
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -57,6 +57,8 @@ def all_reduce_flat(flat: torch.Tensor, group=None, async_op: bool = False):
     """the one exchange step of the path: sum of the flat gradient bucket over ranks"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None
+    if flat.is_cuda and dist.get_backend(group) == "gloo":             # one-GPU rehearsals: through the host
+        return _all_reduce_sum(flat, group)
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
@@ -80,3 +82,107 @@ def data_parallel_step(step_fn: Callable, geo, g0, g1, origins_global, params, t
     out = step_fn(local_geo, g0, g1, org, params, tgt, **step_kw)
     all_reduce_flat(out.flat, group)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Stripe-sharded grids: the exchange shrinks from the whole gradient bucket to one node row per stripe boundary
+# ------------------------------------------------------------------------------------------------------------------------------
+@dataclass
+class StripePlan:
+    """Whole-image passes (every sample of the image/volume once per rank and step): instead of replicating the grids and
+    all-reducing their dense gradients (4K image: 31 MB per step over point-to-point xGMI links), every rank owns a STRIPE of the
+    last sample axis - the slowest spatial axis of the grid tensors ``[C, (Z,) Y, X]`` (fp_def.py:54,76), so a stripe is one
+    contiguous block of node rows per channel - and draws all its ``world`` crops per step from that stripe.  The sample multiset
+    of a step is the same as with replicated grids (every sample ``world`` times, distinct noise ids); a rank reads and updates
+    only the nodes of its stripe, so the only grid gradients two ranks share are the ONE node row of G0 and of G1 on each stripe
+    boundary.  ``exchange`` sums those rows together with the loss and the decoder gradients in one small all-reduce;
+    ``assemble`` rebuilds the full grids from the stripes once, after training.
+
+    Stripes start at multiples of the G1 cell (``g1_cell`` samples), so a boundary is a node row of both grids.
+    """
+    rank: int
+    world: int
+    length: int          # samples along the stripe axis
+    g1_cell: int         # samples per G1 cell along it (2 x the G0 cell)
+    starts: List[int]    # stripe starts (samples), len world + 1; starts[-1] = length
+    _index: dict = field(default_factory=dict, repr=False, compare=False)
+
+    @property
+    def start(self) -> int:
+        return self.starts[self.rank]
+
+    @property
+    def size(self) -> int:
+        return self.starts[self.rank + 1] - self.starts[self.rank]
+
+    def node_rows(self, level: int, rank: Optional[int] = None) -> Tuple[int, int]:
+        """first and last node row (inclusive) of grid ``level`` (0: G0, 1: G1) that the stripe's samples touch"""
+        r = self.rank if rank is None else rank
+        cell = self.g1_cell // 2 if level == 0 else self.g1_cell
+        return self.starts[r] // cell, -(-self.starts[r + 1] // cell)
+
+    def boundary_rows(self, level: int) -> List[int]:
+        cell = self.g1_cell // 2 if level == 0 else self.g1_cell
+        return [s // cell for s in self.starts[1:-1]]
+
+    def boundary_index(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """the boundary rows of G0 and G1 as index tensors on ``device`` (built once per device)"""
+        key = str(device)
+        if key not in self._index:
+            self._index[key] = tuple(torch.tensor(self.boundary_rows(level), dtype=torch.long, device=device) for level in (0, 1))
+        return self._index[key]
+
+
+def plan_stripes(length: int, g1_cell: int, rank: Optional[int] = None, world: Optional[int] = None) -> StripePlan:
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if g1_cell < 2 or g1_cell % 2:
+        raise ValueError("g1_cell must be an even number of samples (2 x the G0 cell)")
+    cells = length // g1_cell
+    if cells < world:
+        raise ValueError(f"{length} samples hold {cells} G1 cells: fewer than {world} ranks")
+    starts = [shard_range(cells, r, world)[0] * g1_cell for r in range(world)] + [int(length)]
+    return StripePlan(int(rank), int(world), int(length), int(g1_cell), starts)
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    """in-place sum over ranks; device tensors go through the host when the group's backend is gloo (one-GPU rehearsals, tests)"""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor, grad_g1: torch.Tensor, group=None) -> None:
+    """The exchange step of a stripe-sharded training step, in place: ``small`` (loss + decoder gradients, a 1-D view of the flat
+    bucket) and the boundary node rows of the two grid gradients become sums over ranks - ONE all-reduce of
+    ``small.numel() + (world - 1) * C * (row of G0 + row of G1)`` floats."""
+    if plan.world == 1:
+        return
+    idx0, idx1 = plan.boundary_index(grad_g0.device)
+    h0, h1 = grad_g0.index_select(1, idx0), grad_g1.index_select(1, idx1)
+    ns, n0 = small.numel(), h0.numel()
+    buf = torch.cat([small.reshape(-1), h0.reshape(-1), h1.reshape(-1)])
+    _all_reduce_sum(buf, group)
+    small.copy_(buf[:ns].view_as(small))
+    grad_g0.index_copy_(1, idx0, buf[ns:ns + n0].view_as(h0))
+    grad_g1.index_copy_(1, idx1, buf[ns + n0:].view_as(h1))
+
+
+def assemble_stripes(plan: StripePlan, g0: torch.Tensor, g1: torch.Tensor, group=None) -> None:
+    """After training: every rank keeps the node rows it owns (from its first row up to, not including, the next stripe's first
+    row; the last rank up to the end of the grid), zeroes the rest, and one all-reduce(sum) gives everyone the full grids.
+    Boundary rows are identical on both neighbours (same summed gradients, same optimiser state), so either copy would do."""
+    if plan.world == 1:
+        return
+    for level, g in ((0, g0), (1, g1)):
+        lo = plan.node_rows(level)[0]
+        hi = plan.node_rows(level, plan.rank + 1)[0] if plan.rank + 1 < plan.world else g.shape[1]
+        keep = g[:, lo:hi].clone()
+        g.zero_()
+        g[:, lo:hi] = keep
+        _all_reduce_sum(g, group)

@@ -806,6 +806,53 @@ def test_kernel_noise_world_size_invariance(dev):
     assert torch.equal(y_all[2048:], y_b)
 
 
+def test_stripe_sharded_step_virtual_ranks(dev):
+    """SURVEY 8e, stripe-sharded grids (distributed.StripePlan): 3 virtual ranks on one GPU, each running the fused kernel on its
+    stripe (3 crops at the same origin, global sample ids), the boundary rows summed as stripe_exchange would.  Every rank's rows ==
+    the CPU oracle on all 9 crops; nothing outside a rank's node rows is touched; loss and decoder gradients add up."""
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.distributed import plan_stripes
+    HH, WW, world = 24, 48, 3
+    g = torch.Generator().manual_seed(11)
+    fp, _ = O.create_pyramid((HH // 4, WW // 4), 12, 8, dim=2, no_mip=True, generator=g)
+    g0, g1 = fp[0].detach(), fp[1].detach()
+    mlp = O.init_mlp(73, 64, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    image = torch.rand(HH, WW, 3, generator=g)
+    plans = [plan_stripes(WW, 8, r, world) for r in range(world)]
+    n_crop = HH * plans[0].size
+    n_global = world * world * n_crop
+    kw = dict(dim=2, method=1, step_number=0.25, mip_level=0, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=3, noise_offset=4,
+              loss_scale=1.0 / (3.0 * n_global))
+    outs = []
+    for pl in plans:
+        geo = fused.PathGeometry(extent=(HH, pl.size), num_crops=world, sample_base=pl.rank * world * n_crop,
+                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, **kw)
+        tgt = image[:, pl.start:pl.start + pl.size].reshape(-1, 3).repeat(world, 1).to(dev)
+        outs.append(fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), [(0, pl.start)] * world, params, tgt))
+    # the oracle on all crops in one go (stripe r `world` times, ranks in order: the same global sample ids)
+    org_all = [(0, pl.start) for pl in plans for _ in range(world)]
+    tgt_all = torch.cat([image[:, pl.start:pl.start + pl.size].reshape(-1, 3).repeat(world, 1) for pl in plans])
+    noise = O.kernel_noise(n_global, 73, 8, seed=3, offset=4, sample_base=0)
+    ref = O.forward_backward(g0, g1, mlp, org_all, (HH, plans[0].size), 0.25, 0, tgt_all, noise, 6, mean_over=n_global)
+    assert_rel(sum(o.loss for o in outs), ref.loss, 2e-6, "loss")
+    for k, nme in enumerate(["W1", "b1", "W2", "b2", "W3", "b3"]):
+        assert_rel(sum(o.grad_mlp[k] for o in outs), ref.grad_mlp[k], 2e-5, nme)
+    for level, name in ((0, "grad_g0"), (1, "grad_g1")):
+        full = sum(getattr(o, name) for o in outs)                         # what the boundary exchange produces on the shared rows
+        refg = getattr(ref, name)
+        for pl, o in zip(plans, outs):
+            lo, hi = pl.node_rows(level)
+            mine = getattr(o, name)
+            assert float(mine[:, :lo].abs().sum()) == 0.0 and float(mine[:, hi + 1:].abs().sum()) == 0.0, "a rank touched rows outside its stripe"
+            own = mine.clone()
+            for b in pl.boundary_rows(level):
+                if lo <= b <= hi:
+                    own[:, b] = full[:, b]
+            err = float((own[:, lo:hi + 1].cpu() - refg[:, lo:hi + 1]).abs().max() / refg.abs().max())
+            assert err < 2e-5, (name, pl.rank, err)
+
+
 # ------------------------------------------------------------------------------------------------ training loop
 def test_training_trajectory_and_psnr(dev):
     """A short fit with the product's loop (fused step reading its targets from the resident uint8 image + the one-launch

@@ -264,3 +264,92 @@ def test_data_parallel_step_matches_single_process_gloo():
         r = torch.load(out)
     err = float((r["dp"] - r["single"]).abs().max() / r["single"].abs().max())
     assert err < 1e-6, err
+
+
+def test_stripe_plans_tile_the_axis():
+    from neural_image_compression_v2_amd.distributed import plan_stripes
+    for length, cell in ((3840, 8), (1080, 8), (64, 2), (100, 4)):
+        for world in (1, 2, 3, 4, 8):
+            if length // cell < world:
+                continue
+            plans = [plan_stripes(length, cell, r, world) for r in range(world)]
+            assert plans[0].start == 0 and plans[-1].start + plans[-1].size == length
+            for a, b in zip(plans, plans[1:]):
+                assert a.start + a.size == b.start and b.start % cell == 0
+                # neighbours share exactly one node row per grid: the boundary row
+                for level in (0, 1):
+                    assert a.node_rows(level)[1] == b.node_rows(level)[0] == a.boundary_rows(level)[a.rank]
+    p = plan_stripes(3840, 8, 7, 8)
+    assert (p.start, p.size, p.node_rows(0), p.node_rows(1)) == (3360, 480, (840, 960), (420, 480))
+    with pytest.raises(ValueError):
+        plan_stripes(16, 8, 0, 4)
+
+
+def _stripe_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from neural_image_compression_v2_amd import _lib, fused
+        from neural_image_compression_v2_amd.distributed import assemble_stripes, plan_stripes, stripe_exchange
+        from oracle import nic_oracle as O
+        torch.set_num_threads(2)
+        HH, WW = 16, 32
+        g = torch.Generator().manual_seed(3)
+        fp, _ = O.create_pyramid((HH // 4, WW // 4), 12, 8, dim=2, no_mip=True, generator=g)          # [12, 9, 5], [12, 5, 3]
+        g0, g1 = fp[0].detach().clone(), fp[1].detach().clone()
+        mlp = O.init_mlp(73, 64, generator=g)
+        image = torch.rand(HH, WW, 3, generator=g)
+        plan = plan_stripes(WW, 8, rank, world)
+        n_crop = HH * plan.size
+        n_global = world * world * n_crop
+
+        def geo_of(num_crops, extent, base):
+            return fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=num_crops,
+                                      noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5, noise_offset=2, sample_base=base,
+                                      loss_scale=1.0 / (3.0 * n_global))
+        # this rank: `world` crops, all of them its stripe
+        geo = geo_of(world, (HH, plan.size), rank * world * n_crop)
+        tgt = image[:, plan.start:plan.start + plan.size].reshape(-1, 3).repeat(world, 1)
+        out = _oracle_step(geo, g0, g1, torch.tensor([[0, plan.start]] * world), mlp.tensors(), tgt)
+        offs, sizes, _ = fused.grad_bucket_layout(geo, g0, g1)
+        stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)
+        # a plain gradient step on everything this rank holds, then the stripes are put together
+        g0 -= 0.5 * out.grad_g0
+        g1 -= 0.5 * out.grad_g1
+        assemble_stripes(plan, g0, g1)
+        # single process: the same crops (stripe r `world` times, ranks in order) with the same global sample ids
+        plans = [plan_stripes(WW, 8, r, world) for r in range(world)]
+        org_all = torch.tensor([[0, p.start] for p in plans for _ in range(world)])
+        tgt_all = torch.cat([image[:, p.start:p.start + p.size].reshape(-1, 3).repeat(world, 1) for p in plans])
+        single = _oracle_step(geo_of(world * world, (HH, plan.size), 0), fp[0].detach(), fp[1].detach(), org_all, mlp.tensors(), tgt_all)
+        lo0, hi0 = plan.node_rows(0)
+        lo1, hi1 = plan.node_rows(1)
+        res = {
+            "small": float((out.flat[:offs[7]] - single.flat[:offs[7]]).abs().max() / single.flat[:offs[7]].abs().max()),
+            "g0": float((out.grad_g0[:, lo0:hi0 + 1] - single.grad_g0[:, lo0:hi0 + 1]).abs().max() / single.grad_g0.abs().max()),
+            "g1": float((out.grad_g1[:, lo1:hi1 + 1] - single.grad_g1[:, lo1:hi1 + 1]).abs().max() / single.grad_g1.abs().max()),
+            "p0": float((g0 - (fp[0].detach() - 0.5 * single.grad_g0)).abs().max()),
+            "p1": float((g1 - (fp[1].detach() - 0.5 * single.grad_g1)).abs().max()),
+            "touched_outside": float(out.grad_g0[:, :lo0].abs().sum() + out.grad_g0[:, hi0 + 1:].abs().sum()),
+        }
+        torch.save(res, out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stripe_sharded_step_matches_single_process_gloo():
+    """2 ranks, grids sharded in stripes of the last sample axis: per-rank oracle steps on the rank's stripe, ONE small all-reduce
+    (loss + decoder grads + the boundary node rows) == the single-process step on the same crops, on every row a rank owns; the
+    assembled grids after an update == the single-process update."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.pt")
+        mp.spawn(_stripe_worker, args=(2, port, out), nprocs=2, join=True)
+        for r in range(2):
+            res = torch.load(out + f".{r}")
+            assert res["touched_outside"] == 0.0, res
+            for k in ("small", "g0", "g1"):
+                assert res[k] < 1e-6, (r, res)
+            assert res["p0"] < 1e-6 and res["p1"] < 1e-6, (r, res)
