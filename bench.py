@@ -125,16 +125,16 @@ def main():
     n_global = n_local * vworld
     stripes = vworld > 1 and args.shard == "stripes"
     if stripes:
-        # rank r: the stripe [start, start + size) of image axis 1, `world` passes over it per step (crops at the same origin)
+        # rank r: the stripe [start, start + size) of image axis 1, `world` passes over it per step (nic_path_desc.passes)
         plan = plan_stripes(W, 8, rank, vworld)                       # G1 cell = 8 pixels at step 1/4
-        extent, ncrops = (H, plan.size), vworld
-        org = torch.tensor([[0, plan.start]] * vworld, dtype=torch.int32, device=dev)
+        extent, ncrops, passes = (H, plan.size), 1, vworld            # one crop, `world` passes: a cell's gradients leave the CU once
+        org = torch.tensor([[0, plan.start]], dtype=torch.int32, device=dev)
         if args.target == "tensor":
             target = img[:, :, plan.start:plan.start + plan.size].permute(1, 2, 0).reshape(-1, 3).repeat(vworld, 1).contiguous().to(dev)
     else:
-        extent, ncrops = (H, W), 1
+        extent, ncrops, passes = (H, W), 1, 1
         org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
-    assert extent[0] * extent[1] * ncrops == n_local
+    assert extent[0] * extent[1] * ncrops * passes == n_local
     offs, sizes, total = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, extent, ncrops), g0, g1)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     tensors = params + [g0, g1]                                       # Adam state per tensor, order of the bucket (after the loss)
@@ -148,7 +148,7 @@ def main():
     adam_tab = (_lib.NicAdamTensor * len(tensors))()
 
     def step(i, events=None):
-        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops,
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, passes=passes,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
                                  sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global),
                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 1
+#define NIC_ABI_VERSION 2
 
 enum {
     NIC_OK = 0,
@@ -82,6 +82,12 @@ typedef struct nic_path_desc {
     int64_t sample_base;     /* global id of this launch's sample 0 (data-parallel shards: keeps the noise world-size invariant) */
     float loss_scale;        /* 1 / (3 * N_global): the MSELoss mean (image_compression.py:259) */
     int32_t flags;           /* NIC_FLAG_* (0 is always valid) */
+    int32_t passes;          /* training entry points: every crop is sampled `passes` times in one launch (0 and 1 = once); pass k of
+                              * crop c has the sample ids (c * passes + k) * n_per_crop + ..., i.e. its own noise and its own target /
+                              * dy rows (N = num_crops * passes * n_per_crop) - the same result as listing the crop `passes` times, but
+                              * a cell's gradients are summed over all passes before they go to memory (stripe-sharded multi-GPU steps).
+                              * Every other entry point: 0 or 1. */
+    int32_t reserved0;       /* 0 */
 } nic_path_desc;
 /* Every crop origin is a multiple of the cell size 1 / step_number (1 when step_number >= 1), e.g. whole-image passes from
  * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1

@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 1
+NIC_ABI_VERSION = 2
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -33,6 +33,7 @@ class NicPathDesc(ctypes.Structure):
         ("g1_nodes", ctypes.c_int32 * 3), ("pe_div", ctypes.c_float * 8), ("noise_mode", ctypes.c_int32),
         ("num_bits", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noise_offset", ctypes.c_uint64),
         ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("flags", ctypes.c_int32),
+        ("passes", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 

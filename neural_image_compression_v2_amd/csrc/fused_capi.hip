@@ -53,8 +53,9 @@ int reduce(int layout, const float* partials, int n_waves, nic_mlp_grads g, floa
     }
 }
 
-int check_geometry(const nic_path_desc* d) {
+int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->num_crops < 1) return NIC_E_SHAPE;
+    if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
     if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
@@ -73,6 +74,7 @@ int check_geometry(const nic_path_desc* d) {
 void balance_units(FusedParams& p, int per_cu) {
     const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * 4;
     p.rg_log2 = 0;
+    // (niter is a power of two, so the groups stay equal with any number of passes)
     while (p.rg_log2 < NIC_RG_MAX && (p.niter >> (p.rg_log2 + 1)) >= 1 && (p.n_tiles << p.rg_log2) < 2 * waves) ++p.rg_log2;
 }
 
@@ -96,7 +98,8 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     const int ez = d->dim == 3 ? d->extent[2] : 1;
     p.d.extent[2] = ez;
     p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * ez;
-    p.n_total = p.n_per_crop * d->num_crops;
+    p.passes = d->passes > 1 ? d->passes : 1;
+    p.n_total = p.n_per_crop * d->num_crops * p.passes;
     // macro-tiles of fi.tx x fi.ty x fi.tz CELL BLOCKS; a cell block = m samples per axis, m = 1 / step_number (1 when the step
     // is >= 1).  The crop origin is not known on the host, so the block count per axis is the unaligned upper bound unless the
     // caller vouches for cell-aligned origins (NIC_FLAG_ORIGINS_ALIGNED); blocks (lanes) that fall outside the crop are masked
@@ -131,6 +134,7 @@ bool mlp_ok(const nic_mlp* m) {
 FusedParams zero_params() {
     FusedParams p;
     ::memset(static_cast<void*>(&p), 0, sizeof(p));
+    p.passes = 1;
     return p;
 }
 
@@ -139,7 +143,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
                 void* workspace, size_t workspace_bytes, void* stream, const nic_target_image* img = nullptr) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
-    int rc = check_geometry(d);
+    int rc = check_geometry(d, true);
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !g0_grad || !g1_grad || !grads || !workspace) return NIC_E_NULL;
     if ((target != nullptr) + (dy != nullptr) + (img != nullptr) != 1) return NIC_E_ARG;

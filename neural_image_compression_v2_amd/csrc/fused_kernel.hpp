@@ -68,7 +68,8 @@ struct FusedParams {
     float* partials;       // workspace, [n_waves][REC]
     int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;
-    int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile
+    int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile and pass
+    int passes;            // training: a macro-tile runs niter * passes rounds (nic_path_desc.passes); round it = pass (it / niter), sample it % niter
     int rg_log2;           // the rounds of a macro-tile are dealt out in 2^rg_log2 groups (work units): small launches balance better
     float grad_scale;      // 2 * loss_scale
 };
@@ -768,7 +769,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         const bool tile_ok = base + wave < t_end;
         const int64_t unit = tile_ok ? base + wave : t_end - 1;
         const int64_t tile = unit >> p.rg_log2;
-        const int it_len = (SRC == SRC_ENCODE ? p.niter : 1) >> p.rg_log2, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * it_len;
+        const int it_len = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> p.rg_log2, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * it_len;
         // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
         int crop = 0;
         int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
@@ -869,9 +870,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         int q[3] = {0, 0, 0};
         if (SRC == SRC_ENCODE) {
             const int m1 = (1 << p.lm) - 1;
+            const int pass = it >> (p.lm * L::DIM), its = it & (p.niter - 1);      // niter = 2^(lm * dim)
             int j[3];
-            if (L::DIM == 2) { j[1] = it & m1; j[0] = it >> p.lm; j[2] = 0; }
-            else { j[2] = it & m1; j[1] = (it >> p.lm) & m1; j[0] = it >> (2 * p.lm); }
+            if (L::DIM == 2) { j[1] = its & m1; j[0] = its >> p.lm; j[2] = 0; }
+            else { j[2] = its & m1; j[1] = (its >> p.lm) & m1; j[0] = its >> (2 * p.lm); }
             const int ez = L::DIM == 3 ? p.d.extent[2] : 1;
             const int ext[3] = {p.d.extent[0], p.d.extent[1], ez};
             int idx[3] = {0, 0, 0};
@@ -883,7 +885,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 idx[a] = i < 0 ? 0 : (i >= ext[a] ? ext[a] - 1 : i);     // masked lanes stay inside the crop
                 q[a] = org[a] + idx[a];
             }
-            n = (int64_t)crop * p.n_per_crop + ((int64_t)idx[0] * ext[1] + idx[1]) * ez + idx[2];
+            n = ((int64_t)crop * p.passes + pass) * p.n_per_crop + ((int64_t)idx[0] * ext[1] + idx[1]) * ez + idx[2];
         } else {
             n = tile * 32 + pl;
             valid = tile_ok && n < p.n_total;

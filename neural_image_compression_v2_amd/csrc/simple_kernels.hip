@@ -341,6 +341,7 @@ static int check_desc_common(const nic_path_desc* d) {
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
     if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
+    if (d->passes < 0 || d->passes > 1) return NIC_E_ARG;             // passes: the fused training entry points only
     return NIC_OK;
 }
 

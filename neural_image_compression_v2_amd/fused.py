@@ -66,6 +66,7 @@ class PathGeometry:
     loss_scale: Optional[float] = None   # default 1 / (3 N)
     flags: int = 0                       # NIC_FLAG_* the caller vouches for (the wrappers add ORIGINS_ALIGNED when they can see it)
     split_bf16: bool = False             # 2D training steps: matrix products as hi + lo bf16 pairs on the bf16 pipe (NIC_FLAG_SPLIT_BF16)
+    passes: int = 1                      # training steps: every crop sampled `passes` times in one launch (nic_path_desc.passes)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -74,6 +75,8 @@ class PathGeometry:
             self.use_tri_pe = False          # fp_def.py:208
         if len(self.extent) != self.dim:
             raise ValueError("extent needs one entry per axis")
+        if int(self.passes) < 1:
+            raise ValueError("passes must be >= 1")
 
     @property
     def n_per_crop(self) -> int:
@@ -84,7 +87,7 @@ class PathGeometry:
 
     @property
     def n_samples(self) -> int:
-        return self.n_per_crop * self.num_crops
+        return self.n_per_crop * self.num_crops * int(self.passes)
 
     @property
     def cin(self) -> int:
@@ -119,6 +122,7 @@ class PathGeometry:
         d.sample_base = int(self.sample_base)
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
+        d.passes = int(self.passes)
         if self.split_bf16 or os.environ.get("NIC_FORCE_SPLIT_BF16") == "1":   # env: test switch for the whole suite
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         return d

@@ -806,9 +806,40 @@ def test_kernel_noise_world_size_invariance(dev):
     assert torch.equal(y_all[2048:], y_b)
 
 
+@pytest.mark.parametrize("dim,method,split", [(2, 1, False), (2, 1, True), (3, 3, False), (3, 4, True)])
+def test_repeated_passes_equal_repeated_crops(dev, dim, method, split):
+    """nic_path_desc.passes: `passes` rounds over every crop in one launch == the same crops listed `passes` times (same global
+    sample ids, so the same noise and target rows; a cell's gradients are summed over the passes before the flush, so only the
+    summation order differs)."""
+    from neural_image_compression_v2_amd import _lib, fused
+    P = 3
+    fp, _ = _pyramid(dim, 64 if dim == 2 else 16, 12, seed=5)
+    g = torch.Generator().manual_seed(8)
+    mlp = O.init_mlp(O.decoder_input_channels(12, 6, dim, method), 64, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    g0, g1 = fp[0].to(dev), fp[1].to(dev)
+    if dim == 2:
+        extent, origins = (24, 40), [(0, 8), (100, 60)]
+    else:
+        extent, origins = (8, 12, 8), [(0, 4, 8), (20, 16, 4)]
+    n_crop = int(np.prod(extent))
+    kw = dict(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=6,
+              noise_offset=2, sample_base=1000, split_bf16=split)
+    target = torch.rand(len(origins) * P * n_crop, 3, generator=g).to(dev)
+    a = fused.fused_forward_backward(fused.PathGeometry(num_crops=len(origins), passes=P, **kw), g0, g1, origins, params, target, want_y=True)
+    listed = [o for o in origins for _ in range(P)]                       # crop-major, then pass: (c * passes + k) * n_per_crop + ...
+    b = fused.fused_forward_backward(fused.PathGeometry(num_crops=len(listed), **kw), g0, g1, listed, params, target, want_y=True)
+    assert torch.equal(a.y, b.y)                                         # per-sample arithmetic is identical
+    assert_rel(a.loss, b.loss, 1e-6, "loss")
+    assert_rel(a.grad_g0, b.grad_g0, 2e-6, "G0 grad")
+    assert_rel(a.grad_g1, b.grad_g1, 2e-6, "G1 grad")
+    for nme, p_, q_ in zip(["W1", "b1", "W2", "b2", "W3", "b3"], a.grad_mlp, b.grad_mlp):
+        assert_rel(p_, q_, 2e-6, nme)
+
+
 def test_stripe_sharded_step_virtual_ranks(dev):
     """SURVEY 8e, stripe-sharded grids (distributed.StripePlan): 3 virtual ranks on one GPU, each running the fused kernel on its
-    stripe (3 crops at the same origin, global sample ids), the boundary rows summed as stripe_exchange would.  Every rank's rows ==
+    stripe (one crop, 3 passes, global sample ids), the boundary rows summed as stripe_exchange would.  Every rank's rows ==
     the CPU oracle on all 9 crops; nothing outside a rank's node rows is touched; loss and decoder gradients add up."""
     from neural_image_compression_v2_amd import _lib, fused
     from neural_image_compression_v2_amd.distributed import plan_stripes
@@ -826,10 +857,10 @@ def test_stripe_sharded_step_virtual_ranks(dev):
               loss_scale=1.0 / (3.0 * n_global))
     outs = []
     for pl in plans:
-        geo = fused.PathGeometry(extent=(HH, pl.size), num_crops=world, sample_base=pl.rank * world * n_crop,
+        geo = fused.PathGeometry(extent=(HH, pl.size), num_crops=1, passes=world, sample_base=pl.rank * world * n_crop,
                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, **kw)
         tgt = image[:, pl.start:pl.start + pl.size].reshape(-1, 3).repeat(world, 1).to(dev)
-        outs.append(fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), [(0, pl.start)] * world, params, tgt))
+        outs.append(fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), [(0, pl.start)], params, tgt))
     # the oracle on all crops in one go (stripe r `world` times, ranks in order: the same global sample ids)
     org_all = [(0, pl.start) for pl in plans for _ in range(world)]
     tgt_all = torch.cat([image[:, pl.start:pl.start + pl.size].reshape(-1, 3).repeat(world, 1) for pl in plans])

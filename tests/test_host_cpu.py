@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nicv2_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.nic_abi_version() == 1
+    assert lib.nic_abi_version() == 2
     assert lib.nic_error_string(-2).decode().startswith("unsupported")
     assert lib.nic_decoder_input_channels(2, 1, 12, 6) == 73          # var2.py:114-118
     assert lib.nic_decoder_input_channels(3, 3, 12, 6) == 127
@@ -110,6 +110,15 @@ def test_argument_errors_are_reported_before_any_gpu_work(lib):
     gs = _lib.NicMlpGrads()
     assert lib.nic_fused_forward_backward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null, fake, fake, fake,
                                           ctypes.byref(gs), fake, 16, null) == E_WORKSPACE
+    d.passes = 2                                            # repeated passes exist for the training entry points only
+    assert lib.nic_fused_forward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null) == E_ARG
+    assert lib.nic_encode(ctypes.byref(d), fake, fake, fake, fake, null) == E_ARG
+    assert lib.nic_fused_forward_backward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null, fake, fake, fake,
+                                          ctypes.byref(gs), fake, 16, null) == E_WORKSPACE          # accepted there
+    d.passes = -1
+    assert lib.nic_fused_forward_backward(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), null, fake, null, fake, fake, fake,
+                                          ctypes.byref(gs), fake, 16, null) == E_ARG
+    d.passes = 0
     d.noise_mode = _lib.NIC_NOISE_KERNEL
     assert lib.nic_fused_forward_u8(ctypes.byref(d), fake, fake, fake, ctypes.byref(m), fake, null, null) == E_ARG    # decoding adds no noise
     assert lib.nic_adam_multi(None, 3, 0.9, 0.999, 1e-8, null) == E_NULL
