@@ -156,6 +156,8 @@ def main():
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
         if world > 1 and stripes:
             stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)   # RCCL sum of [loss | decoder grads | boundary rows]
+        elif stripes:                                                 # --virtual-world: the pack / unpack launches without the collective
+            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1, reduce=lambda t, g: None)
         else:
             all_reduce_flat(out.flat)                                 # RCCL sum of [loss | decoder grads | grid grads]
         cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))  # CosineAnnealingLR(T_max), eta_min = 0

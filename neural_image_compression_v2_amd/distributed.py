@@ -157,7 +157,8 @@ def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor, grad_g1: torch.Tensor, group=None) -> None:
+def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor, grad_g1: torch.Tensor, group=None,
+                    reduce: Optional[Callable] = None) -> None:
     """The exchange step of a stripe-sharded training step, in place: ``small`` (loss + decoder gradients, a 1-D view of the flat
     bucket) and the boundary node rows of the two grid gradients become sums over ranks - ONE all-reduce of
     ``small.numel() + (world - 1) * C * (row of G0 + row of G1)`` floats."""
@@ -167,7 +168,7 @@ def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor
     h0, h1 = grad_g0.index_select(1, idx0), grad_g1.index_select(1, idx1)
     ns, n0 = small.numel(), h0.numel()
     buf = torch.cat([small.reshape(-1), h0.reshape(-1), h1.reshape(-1)])
-    _all_reduce_sum(buf, group)
+    (reduce or _all_reduce_sum)(buf, group)                                 # `reduce`: test / rehearsal hook
     small.copy_(buf[:ns].view_as(small))
     grad_g0.index_copy_(1, idx0, buf[ns:ns + n0].view_as(h0))
     grad_g1.index_copy_(1, idx1, buf[ns + n0:].view_as(h1))
