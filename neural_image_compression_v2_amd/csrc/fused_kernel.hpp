@@ -30,6 +30,9 @@
 //     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
+#ifndef NIC_STAGGER
+#define NIC_STAGGER 1
+#endif
 #ifndef NIC_HOIST_INFER
 #define NIC_HOIST_INFER -1  // inference: -1 = by layout (4-corner G0 layouts: both grids; 3D method 3: G0 only - 96 raw values per lane spill at 2 waves per SIMD)
 #endif
@@ -763,13 +766,28 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     unsigned long long stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    for (int64_t base = t_begin + (int64_t)(blockIdx.x >> 3) * 4; base < t_end; base += lstride) {
+    // Staggered flushes (training): every wave of the chip does the same work per round, so without this all 1 024 waves reach the
+    // grid-gradient flush of their macro-tile in the same few thousand cycles - and a no-return atomic instruction that costs its
+    // wave ~75 ticks when a half or a quarter of the chip flushes costs ~420 when everybody does (ab/micro/atomic_burst.hip).
+    // Workgroups therefore run in four phases: phase f starts its first unit at round f * rounds / 4 and comes back for the rounds it
+    // skipped after its last unit (one extra, partial unit: same work for every wave, no idle time), which keeps the phases
+    // f * rounds / 4 apart for the whole launch.
+    const int64_t base0 = t_begin + (int64_t)(blockIdx.x >> 3) * 4;
+    const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
+    const int rounds_unit = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> p.rg_log2;
+    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && p.rg_log2 == 0) ? (int)((blockIdx.x >> 3) & 3) * (rounds_unit >> 2) : 0;
+    for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
+        const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
         // last tile with every lane masked, which contributes exact zeros everywhere
         const bool tile_ok = base + wave < t_end;
         const int64_t unit = tile_ok ? base + wave : t_end - 1;
         const int64_t tile = unit >> p.rg_log2;
-        const int it_len = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> p.rg_log2, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * it_len;
+        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * rounds_unit;
+        if (shift) {
+            if (kk == 0) { it_begin += shift; it_len -= shift; }          // the first unit without its first `shift` rounds ..
+            else if (kk == n_my) it_len = shift;                         // .. which are done at the very end
+        }
         // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
         int crop = 0;
         int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
