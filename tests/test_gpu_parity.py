@@ -783,6 +783,18 @@ def test_full_size_4k_properties(dev):
     assert_rel(b.grad_g1, a.grad_g1, 1e-4, "tiling: G1 grad")
     for nme, p_, q_ in zip(["W1", "b1", "W2", "b2", "W3", "b3"], b.grad_mlp, a.grad_mlp):
         assert_rel(p_, q_, 1e-4, "tiling: " + nme)
+    # (c2) two passes over the image in one launch (nic_path_desc.passes; staggered flush phases, no round groups at this size)
+    #      == the image listed twice, noise on: same global sample ids
+    tgt2 = torch.cat([target, target.flip(0)])
+    pa = fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, passes=2, **kw),
+                                      g0d, g1d, [(0, 0)], params, tgt2)
+    pb = fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=2, **kw),
+                                      g0d, g1d, [(0, 0), (0, 0)], params, tgt2)
+    assert_rel(pa.loss, pb.loss, 1e-5, "passes: loss")
+    assert_rel(pa.grad_g0, pb.grad_g0, 1e-4, "passes: G0 grad")
+    assert_rel(pa.grad_g1, pb.grad_g1, 1e-4, "passes: G1 grad")
+    for nme, p_, q_ in zip(["W1", "b1", "W2", "b2", "W3", "b3"], pa.grad_mlp, pb.grad_mlp):
+        assert_rel(p_, q_, 1e-4, "passes: " + nme)
     # (d)
     a2 = fused.fused_forward_backward(geo1, g0d, g1d, [(0, 0)], params, target)
     assert_rel(a2.loss, a.loss, 1e-6, "run to run: loss")
