@@ -58,6 +58,11 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
+    // the kernels address a grid element as (wave-uniform channel-plane base) + (32-bit byte offset of the lane): a G0 channel
+    // plane, and 7 G1 channel planes (the lane-half term of the G1 offsets), must stay below 4 GiB
+    int64_t n0 = 1, n1 = 1;
+    for (int a = 0; a < d->dim; ++a) { n0 *= d->g0_nodes[a]; n1 *= d->g1_nodes[a]; }
+    if (n0 >= (int64_t)1 << 30 || 7 * n1 >= (int64_t)1 << 30) return NIC_E_UNSUPPORTED;
     if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
     if (d->g1_weight_mode < 0 || d->g1_weight_mode > 2 || d->noise_mode < 0 || d->noise_mode > 2) return NIC_E_ARG;
     return NIC_OK;

@@ -342,7 +342,10 @@ __device__ __forceinline__ float grid_elem(const FusedParams& p, const float* ba
         const float q = mul_rn(n, p.dq_rcp);
         return fmaf(fmaf(-q, p.dq_den, n), p.dq_rcp, q);
     } else {
-        return (base + plane_off)[voff];
+        // wave-uniform plane base (scalar registers) + a 32-bit BYTE offset per lane: the `global_load_dword v, v_off, s[base]` form,
+        // no 64-bit vector address arithmetic per load (the host checks that the byte offsets fit 32 bits)
+        const char* b = reinterpret_cast<const char*>(base + plane_off);
+        return *reinterpret_cast<const float*>(b + (uint32_t)(voff * 4u));
     }
 }
 
