@@ -30,6 +30,9 @@
 //     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
+#ifndef NIC_GX
+#define NIC_GX 1
+#endif
 #ifndef NIC_STAGGER
 #define NIC_STAGGER 1
 #endif
@@ -581,11 +584,12 @@ struct GridAcc {
 };
 
 template <class L, int NT>
-__device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, const EncCtx& cx, const f32x16 (&dxacc)[NT], GridAcc<L>& ga) {
+__device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, const EncCtx& cx, const f32x16 (&dxacc)[NT], GridAcc<L>& ga,
+                                                      int carried = 0) {
     constexpr int D = L::DIM;
     constexpr int NG0 = GridAcc<L>::NG0, K1 = GridAcc<L>::K1;
 #pragma unroll
-    for (int s = 0; s < NG0; ++s) ga.g0[s] += dxacc[s >> 4][s & 15];
+    for (int s = 0; s < NG0; ++s) ga.g0[s] = s < carried ? dxacc[s >> 4][s & 15] : ga.g0[s] + dxacc[s >> 4][s & 15];   // carried: the tile already holds the sum
     const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
 #pragma unroll
     for (int q = 0; q < K1; ++q) {
@@ -1270,6 +1274,13 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             f32x16 dxacc[NGT];
 #pragma unroll
             for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = f32x16(0.f);
+            // the first 16 G0 slots are a whole accumulator tile: their running sums over the rounds ride in the matrix pipe's C
+            // operand (no vector add, and the sums never have to leave the accumulator registers)
+            constexpr bool GX = NIC_GX && GridAcc<L>::NG0 >= 16;
+            if (GX) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) dxacc[0][s] = gacc.g0[s];
+            }
             auto loadw = [&](int ks, Frag2 (&af)[NGT]) {
 #pragma unroll
                 for (int tg = 0; tg < NGT; ++tg) {
@@ -1289,7 +1300,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 for (int tg = 0; tg < NGT; ++tg) dxacc[tg] = mfma_split(afq[ks & 1][tg], bf, dxacc[tg]);
                 NIC_DW_SB;
             }
-            accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc);            // masked lanes carry exact zeros (dZ3 = 0)
+            accumulate_grid_grads<L, NGT>(p, cx, dxacc, gacc, GX ? 16 : 0);  // masked lanes carry exact zeros (dZ3 = 0)
         }
         STAMP(7);    // dX (+ dZ1 image), grid-gradient accumulation
         wg_lds_barrier();
