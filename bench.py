@@ -134,7 +134,8 @@ def main():
     else:
         extent, ncrops, passes = (H, W), 1, 1
         org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
-    assert extent[0] * extent[1] * ncrops * passes == n_local
+    n_mine = extent[0] * extent[1] * ncrops * passes                  # = n_local unless the stripes are uneven (W / 8 px not a multiple of N)
+    base_mine = H * plan.start * vworld if stripes else rank * n_local   # global id of this rank's first sample
     offs, sizes, total = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, extent, ncrops), g0, g1)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     tensors = params + [g0, g1]                                       # Adam state per tensor, order of the bucket (after the loss)
@@ -150,7 +151,7 @@ def main():
     def step(i, events=None):
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, passes=passes,
                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
-                                 sample_base=rank * n_local, loss_scale=1.0 / (3.0 * n_global),
+                                 sample_base=base_mine, loss_scale=1.0 / (3.0 * n_global),
                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell
                                  split_bf16=args.precision == "split")
         out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
@@ -208,8 +209,8 @@ def main():
                    + (" (virtual: one process, no collectives)" if world == 1 else ""))
         else:
             par = f"dp{world} (sample-sharded, replicated parameters" + (f", {4 * total} B all-reduced per step)" if world > 1 else ")")
-        flops = FLOP_PER_SAMPLE * n_local / (kern_ms * 1e-3) / 1e12
-        gbs = BYTES_PER_SAMPLE * n_local / (kern_ms * 1e-3) / 1e9
+        flops = FLOP_PER_SAMPLE * n_mine / (kern_ms * 1e-3) / 1e12
+        gbs = BYTES_PER_SAMPLE * n_mine / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")            # HBM bytes per launch from the rocprofv3 --pmc passes, if collected
         if os.path.exists(tp):
@@ -229,7 +230,7 @@ def main():
                        "final_loss": round(loss, 6), "psnr_db_after_these_steps": round(psnr, 3)},
         }
         common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,
-                  "samples_per_launch": n_local}
+                  "samples_per_launch": n_mine}
         hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
         if args.precision == "f32":
             # fp32: the matrix pipe is the tighter roofline (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s vs HBM 8 TB/s / 1 164 B = 6.9 Gpx/s)
