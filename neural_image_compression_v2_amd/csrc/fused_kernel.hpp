@@ -30,6 +30,9 @@
 //     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
+#ifndef NIC_STAGGER_RG
+#define NIC_STAGGER_RG 1      // also when the rounds of a macro-tile are dealt out in groups (small launches)
+#endif
 #ifndef NIC_PHASES
 #define NIC_PHASES 4
 #endif
@@ -785,7 +788,8 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     const int64_t base0 = t_begin + (int64_t)(blockIdx.x >> 3) * 4;
     const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
     const int rounds_unit = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> p.rg_log2;
-    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && p.rg_log2 == 0) ? (int)((blockIdx.x >> 3) & (NIC_PHASES - 1)) * (rounds_unit / NIC_PHASES) : 0;
+    const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);      // phases (a power of two)
+    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && (NIC_STAGGER_RG || p.rg_log2 == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
     for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
         const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
