@@ -69,18 +69,25 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 }
 
 // persistent grid: a multiple of 8 blocks (one slice of the tile range per XCD), at most `per_cu` per CU
-// Small launches: when the macro-tiles do not fill the persistent grid at least twice, deal their rounds out in 2 or 4 groups
-// (a macro-tile of the default 8 x 256^2 step is 16 rounds of ~25K cycles; 1 320 of them on 1 024 waves left a third of the
-// waves idle for the second half: 0.41 -> 0.36 ms per step with 2 groups).  Each group flushes its own grid-gradient sums,
-// so more groups than the balance needs cost time (4 groups: 0.41 ms again).
+// Small launches: a wave does whole work units, so with few macro-tiles the time is ceil(units / waves) x unit length - the default
+// 8 x 256^2 step (1 080 macro-tiles of 16 rounds on 1 024 waves) would take 2 x 16 rounds.  The rounds of a macro-tile are therefore
+// dealt out in 2 or 4 groups (work units on neighbouring waves of ONE workgroup: their grid-gradient sums are added through LDS and
+// flushed once) when that shortens the longest wave: 3 x 8 or 5 x 4 rounds here.  Every unit pays its setup, the LDS sum and a share of
+// the flush (~ a quarter of a round); more than 4 groups would put the groups of one macro-tile into different workgroups, which then
+// flush the same nodes at the same time (measured: 8 / 16 groups 0.54 / 0.96 ms against 0.30).
 #ifndef NIC_RG_MAX
 #define NIC_RG_MAX 2
 #endif
 void balance_units(FusedParams& p, int per_cu) {
     const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * 4;
+    const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
-    // (niter is a power of two, so the groups stay equal with any number of passes)
-    while (p.rg_log2 < NIC_RG_MAX && (p.niter >> (p.rg_log2 + 1)) >= 1 && (p.n_tiles << p.rg_log2) < 2 * waves) ++p.rg_log2;
+    double best = 0.0;
+    for (int rg = 0; rg <= NIC_RG_MAX && (p.niter >> rg) >= 1; ++rg) {
+        const int64_t units = p.n_tiles << rg;
+        const double cost = (double)((units + waves - 1) / waves) * ((double)(rounds >> rg) + 0.25);
+        if (rg == 0 || cost < best * 0.98) { best = cost; p.rg_log2 = rg; }     // finer only when it pays at least 2 %
+    }
 }
 
 int grid_for(int64_t n_tiles, int per_cu) {
@@ -115,10 +122,25 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     for (int a = 0; a < d->dim; ++a) p.niter *= m;
     const bool aligned = (d->flags & NIC_FLAG_ORIGINS_ALIGNED) != 0;
     auto blocks = [&](int extent) { return (extent + m - 1) / m + ((m > 1 && !aligned) ? 1 : 0); };
-    const int tx = (blocks(d->extent[0]) + fi.tx - 1) / fi.tx, ty = (blocks(d->extent[1]) + fi.ty - 1) / fi.ty,
-              tz = d->dim == 3 ? (blocks(ez) + fi.tz - 1) / fi.tz : 1;
+    const int bx = blocks(d->extent[0]), by = blocks(d->extent[1]);
+    const int ty = (by + fi.ty - 1) / fi.ty, tz = d->dim == 3 ? (blocks(ez) + fi.tz - 1) / fi.tz : 1;
+    // the remainder column along x: as regular tiles when it holds more than half a tile's blocks, otherwise as edge tiles of
+    // 2^lw x (32 >> lw) blocks (see FusedParams)
+    p.full_x = bx / fi.tx;
+    const int rem = bx - p.full_x * fi.tx;
+    p.edge_lw = -1;
+    int64_t edge_tiles = 0;
+    if (rem > fi.tx / 2) {
+        p.full_x += 1;
+    } else if (rem > 0) {
+        p.edge_lw = 0;
+        while ((1 << p.edge_lw) < rem) ++p.edge_lw;
+        const int eh = 32 >> p.edge_lw;                                // blocks along y per edge tile
+        edge_tiles = (int64_t)((by + eh - 1) / eh) * tz;
+    }
     p.tiles_y = ty; p.tiles_z = tz;
-    p.tiles_per_crop = (int64_t)tx * ty * tz;
+    p.tiles_main = (int64_t)p.full_x * ty * tz;
+    p.tiles_per_crop = p.tiles_main + edge_tiles;
     p.n_tiles = p.tiles_per_crop * d->num_crops;
     p.rg_log2 = 0;
     p.noise.mode = d->noise_mode;

@@ -83,6 +83,12 @@ struct FusedParams {
     float* partials;       // workspace, [n_waves][REC]
     int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;
+    // Edge tiles: when the last column of macro-tiles along x would hold at most 8 of its 16 cell blocks (always so for an unaligned
+    // crop of a power-of-two extent: 64 + 1 blocks), that column is covered by tiles of 2^edge_lw x 32 / 2^edge_lw blocks instead
+    // (1 x 32, 2 x 16, 4 x 8 or 8 x 4): 3 tiles instead of 33 for the 65 x 65 blocks of an unaligned 256^2 crop.  Tiles
+    // [0, tiles_main) of a crop are the regular ones (full_x columns), the rest the edge tiles; edge_lw < 0: none.
+    int64_t tiles_main;
+    int full_x, edge_lw;
     int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile and pass
     int passes;            // training: a macro-tile runs niter * passes rounds (nic_path_desc.passes); round it = pass (it / niter), sample it % niter
     int rg_log2;           // the rounds of a macro-tile are dealt out in 2^rg_log2 groups (work units): small launches balance better
@@ -617,12 +623,13 @@ __device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, cons
 // axis, when it is inside the wave's block and really has the same G1 cell (clamped cells, odd alignment) - and only the
 // even-coordinate lane keeps the sum; the others are left with exact zeros, which the flush skips.
 template <class L>
-__device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, const int (&blk)[3], int lane) {
+__device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, const int (&blk)[3], int lane, int lw) {
     constexpr int D = L::DIM;
-    constexpr int T[3] = {L::TX, L::TY, L::TZ};
-    constexpr int STR[3] = {1, L::TX, L::TX * L::TY};
+    static_assert(L::TX * L::TY == 32 && L::TZ == 1, "a wave block is 2^lw x 32 / 2^lw x 1 cell blocks");
+    const int T[3] = {1 << lw, 32 >> lw, 1};                  // lw = 4 for the regular tiles (TX x TY), smaller for edge tiles
+    const int STR[3] = {1, 1 << lw, 32};
     const int pl = lane & 31;
-    const int lc[3] = {pl % L::TX, (pl / L::TX) % L::TY, pl / (L::TX * L::TY)};
+    const int lc[3] = {pl & (T[0] - 1), pl >> lw, 0};
 #pragma unroll
     for (int a = 0; a < D; ++a) {
         const bool odd = blk[a] & 1;
@@ -770,7 +777,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
     // work unit = (macro-tile, group of rounds); units of one macro-tile are consecutive, so they land on the waves of one workgroup
     const int64_t n_units = p.n_tiles << p.rg_log2;
-    const int64_t chunk = (n_units + 7) >> 3;
+    const int64_t chunk = (((n_units + 7) >> 3) + 3) & ~(int64_t)3;      // a multiple of 4: the groups of a macro-tile stay in one workgroup
     const int64_t t_begin = xcd * chunk;
     const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
     const int lstride = nb8 * 4;
@@ -806,25 +813,36 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             else if (kk == n_my) it_len = shift;                         // .. which are done at the very end
         }
         // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
-        int crop = 0;
+        int crop = 0, lw = 4;                                       // lw: log2 of the lane block's x extent (TX = 16)
+        static_assert(L::TX == 16, "lw");
         int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
         if (SRC == SRC_ENCODE) {
             crop = (int)(tile / p.tiles_per_crop);
             int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
-            int lc[3], tc[3];
-            if (L::DIM == 2) {
-                lc[0] = pl % L::TX; lc[1] = pl / L::TX; lc[2] = 0;              // x fastest: x is the grids' contiguous axis
-                tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y; tc[2] = 0;
+            // regular tile: TX x TY blocks, x fastest (x is the grids' contiguous axis); edge tile: 2^lw x 32 / 2^lw blocks
+            int boff[3];                                                          // the tile's first block inside the crop
+            if (p.edge_lw < 0 || tt < p.tiles_main) {
+                int tc[3];
+                if (L::DIM == 2) {
+                    tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y; tc[2] = 0;
+                } else {
+                    tc[2] = tt % p.tiles_z; tt /= p.tiles_z;
+                    tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y;
+                }
+                boff[0] = tc[0] * L::TX; boff[1] = tc[1] * L::TY; boff[2] = tc[2] * L::TZ;
             } else {
-                lc[0] = pl % L::TX; lc[1] = (pl / L::TX) % L::TY; lc[2] = pl / (L::TX * L::TY);
-                tc[2] = tt % p.tiles_z; tt /= p.tiles_z;
-                tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y;
+                int e = tt - (int)p.tiles_main;
+                lw = p.edge_lw;
+                boff[2] = L::DIM == 3 ? e % p.tiles_z : 0;
+                if (L::DIM == 3) e /= p.tiles_z;
+                boff[1] = e * (32 >> lw);
+                boff[0] = p.full_x * L::TX;
             }
-            constexpr int T[3] = {L::TX, L::TY, L::TZ};
+            const int lc[3] = {pl & ((1 << lw) - 1), pl >> lw, 0};
 #pragma unroll
             for (int a = 0; a < L::DIM; ++a) {
                 org[a] = p.origins[crop * L::DIM + a];
-                blk[a] = (org[a] >> p.lm) + tc[a] * T[a] + lc[a];
+                blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
         }
         GridAcc<L> gacc;
@@ -1672,7 +1690,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
         if (SRC == SRC_ENCODE && TRAIN) {
-            combine_g1_lanes<L>(gacc, blk_off1, blk, lane);
+            combine_g1_lanes<L>(gacc, blk_off1, blk, lane, lw);
             bool flush = true;
             // Small launches deal the rounds of a macro-tile out in groups (work units) on neighbouring waves.  Left alone, those
             // waves flush the SAME nodes in the same few thousand cycles (4 / 8 / 16 groups of the default 8 x 256^2 step: 0.35 / 0.54 /
