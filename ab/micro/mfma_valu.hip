@@ -18,6 +18,8 @@ __device__ __forceinline__ void filler(float (&f)[8], unsigned (&u)[8]) {
         if (KIND == 5) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(u[i & 7]));
         if (KIND == 6) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(f[i & 7]));
         if (KIND == 7) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(u[i & 7]));
+        if (KIND == 8) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(f[i & 7]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 9) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u[i & 7]) : "v"(f[(i + 1) & 7]));
     }
 }
 
@@ -81,6 +83,10 @@ int main(int argc, char**) {
     SWEEP(2, 0, "mfma32x32x16bf16 + v_fma_f32")
     SWEEP(2, 3, "mfma32x32x16bf16 + v_pk_fma_f32")
     SWEEP(4, 0, "mfma32x32x16bf16 one chain + v_fma")
+    SWEEP(0, 8, "no mfma + v_dot2c_f32_bf16")
+    SWEEP(2, 8, "mfma32x32x16bf16 + v_dot2c_f32_bf16")
+    SWEEP(0, 9, "no mfma + v_cvt_pk_bf16_f32")
+    SWEEP(2, 9, "mfma32x32x16bf16 + v_cvt_pk_bf16_f32")
     if (argc > 1) return 0;
     return 0;
 }
