@@ -275,6 +275,54 @@ def test_fused_forward_backward_matches_oracle(dev, case):
         assert torch.equal(a, b), "decoder gradients are bit-stable run to run"
 
 
+def _random_fused_cases(n2=10, n3=6, seed=2025):
+    """random crop extents / origins: every remainder of cell blocks along x (edge tiles of 1, 2, 4, 8 blocks), partial border
+    cells, one to three crops, both precisions of the products"""
+    rs = np.random.RandomState(seed)
+    cases = []
+    for i in range(n2):
+        ext = (int(rs.randint(1, 150)), int(rs.randint(1, 60)))
+        org = [(int(rs.randint(0, 256 - ext[0] + 1)), int(rs.randint(0, 256 - ext[1] + 1))) for _ in range(int(rs.randint(1, 4)))]
+        cases.append((2, 1, bool(i & 1), 64, ext, org, "kernel" if i % 3 else "none", bool(i & 2)))
+    for i in range(n3):
+        ext = (int(rs.randint(1, 40)), int(rs.randint(1, 12)), int(rs.randint(1, 8)))
+        org = [tuple(int(rs.randint(0, 64 - e + 1)) for e in ext) for _ in range(int(rs.randint(1, 3)))]
+        cases.append((3, 3 + (i & 1), True, 16, ext, org, "kernel", bool(i & 2)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_fused_cases(), ids=lambda c: f"d{c[0]}m{c[1]}-{'x'.join(map(str, c[4]))}-{len(c[5])}crops-{'split' if c[7] else 'f32'}")
+def test_fused_random_shapes_match_oracle(dev, case):
+    from neural_image_compression_v2_amd import _lib, fused
+    dim, method, tri, base, extent, origins, noise_kind, split = case
+    if dim == 3:
+        tri = method == 3
+    fp, _ = _pyramid(dim, base, 12, seed=13)
+    g0, g1 = fp[0], fp[1]
+    cin = O.decoder_input_channels(12, 6, dim, method)
+    g = torch.Generator().manual_seed(79)
+    mlp = O.init_mlp(cin, 64, generator=g)
+    n = len(origins) * int(np.prod(extent))
+    target = torch.rand(n, 3, generator=g)
+    noise, kw = None, {}
+    if noise_kind == "kernel":
+        noise = O.kernel_noise(n, cin, 8, seed=99, offset=3, sample_base=0)
+        kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=99, noise_offset=3)
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, 6, method=method, use_tri_pe=tri)
+    geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                             split_bf16=split, **kw)
+    params = [q.to(dev) for q in mlp.tensors()]
+    out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), want_y=True)
+    assert_rel(out.y, ref.y, 5e-6, "y")
+    assert_rel(out.loss, ref.loss, 1e-5, "loss")
+    assert_rel(out.grad_g0, ref.grad_g0, 1e-4, "grad G0")
+    assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "grad G1")
+    for nme, a, b in zip(["W1", "b1", "W2", "b2", "W3", "b3"], out.grad_mlp, ref.grad_mlp):
+        assert_rel(a, b, 1e-4, nme)
+    if noise_kind == "none":                                        # decode of the same crops (inference kernel, 2 workgroups per CU)
+        assert_rel(fused.fused_forward(geo, g0.to(dev), g1.to(dev), origins, params), ref.y, 5e-6, "fused forward")
+
+
 @pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: f"split-d{c[0]}m{c[1]}-{c[3]}-{'x'.join(map(str, c[4]))}-{c[6]}".replace(" ", ""))
 def test_split_bf16_training_step(dev, case):
     """NIC_FLAG_SPLIT_BF16 (2D: every matrix product of the training step as hi + lo bf16 pairs on the bf16 matrix pipe; 3D: the four
