@@ -8,6 +8,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int KIND, int K>
 __device__ __forceinline__ void filler(float (&f)[8], unsigned (&u)[8]) {
+    unsigned u_s = 0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[i & 7]));
@@ -18,6 +19,11 @@ __device__ __forceinline__ void filler(float (&f)[8], unsigned (&u)[8]) {
         if (KIND == 5) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(u[i & 7]));
         if (KIND == 6) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(f[i & 7]));
         if (KIND == 7) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(u[i & 7]));
+        if (KIND == 10) asm volatile("s_nop 0");
+        if (KIND == 11) asm volatile("s_waitcnt lgkmcnt(0)");
+        if (KIND == 12) asm volatile("s_add_u32 %0, %0, 1" : "+s"(u_s));
+        if (KIND == 13) asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %0, a0" : "+v"(u[i & 7]) : : "a0");
+        if (KIND == 14) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
         if (KIND == 8) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(f[i & 7]) : "v"(u[(i + 1) & 7]));
         if (KIND == 9) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u[i & 7]) : "v"(f[(i + 1) & 7]));
     }
@@ -83,6 +89,11 @@ int main(int argc, char**) {
     SWEEP(2, 0, "mfma32x32x16bf16 + v_fma_f32")
     SWEEP(2, 3, "mfma32x32x16bf16 + v_pk_fma_f32")
     SWEEP(4, 0, "mfma32x32x16bf16 one chain + v_fma")
+    SWEEP(0, 10, "no mfma + s_nop 0")
+    SWEEP(0, 11, "no mfma + s_waitcnt lgkmcnt(0)")
+    SWEEP(0, 14, "no mfma + s_waitcnt vmcnt(0) lgkmcnt(0)")
+    SWEEP(0, 12, "no mfma + s_add_u32")
+    SWEEP(0, 13, "no mfma + accvgpr write+read pair")
     SWEEP(0, 8, "no mfma + v_dot2c_f32_bf16")
     SWEEP(2, 8, "mfma32x32x16bf16 + v_dot2c_f32_bf16")
     SWEEP(0, 9, "no mfma + v_cvt_pk_bf16_f32")
