@@ -17,7 +17,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnicv2_hip.so")
 SOURCES = ["simple_kernels.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip"]
 HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: MFMA results that vector instructions consume may live in the architectural VGPRs instead of bouncing
+# through v_accvgpr_read / write (split training kernel: 656 -> 423 of them, -0.7 %; fp32 2D 18 -> 0 spills; 3D 170 -> 115 / 135 -> 85)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
