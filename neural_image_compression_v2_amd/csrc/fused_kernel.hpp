@@ -1283,10 +1283,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         {
             auto load2 = [&](int ksw, Frag2& af, Frag2& bf) {             // k-step = (source wave, 16 samples)
                 const int off = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB;
+                // issue order = reverse order of first use (mfma_split starts with lo x hi): one s_waitcnt per step, and an
+                // s_waitcnt costs a lone wave an issue slot like any other instruction
                 af.hi = frag_trs<S::LDZB>(&dz_tr[off + 32 * to2]);
+                bf.lo = frag_trs<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
                 af.lo = frag_trs<S::LDZB>(&dz_tr[off + S::BZ + 32 * to2]);
                 bf.hi = frag_trs<S::LDZB>(&a1_tr[off + 32 * tk2]);
-                bf.lo = frag_trs<S::LDZB>(&a1_tr[off + S::BZ + 32 * tk2]);
             };
             Frag2 af[2], bf[2];                                            // fragments of step k + 1 are in flight during step k
             load2(0, af[0], bf[0]);
@@ -1342,9 +1344,9 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             auto load1 = [&](int ksw, Frag2& af, Frag2& bf) {
                 const int offz = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDZB, offx = (ksw >> 1) * S::SPW + 4 * (ksw & 1) * S::LDXB;
                 af.hi = frag_trs<S::LDZB>(&dz_tr[offz + 32 * to1]);
+                bf.lo = frag_trs<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
                 af.lo = frag_trs<S::LDZB>(&dz_tr[offz + S::BZ + 32 * to1]);
                 bf.hi = frag_trs<S::LDXB>(&x_tr[offx + 64 * c2 + 32 * tk1]);
-                bf.lo = frag_trs<S::LDXB>(&x_tr[offx + S::BX + 64 * c2 + 32 * tk1]);
             };
             Frag2 af[2], bf[2];
             load1(0, af[0], bf[0]);
