@@ -51,6 +51,9 @@
 #ifndef NIC_HOIST_INFER
 #define NIC_HOIST_INFER -1  // inference: -1 = by layout (4-corner G0 layouts: both grids; 3D method 3: G0 only - 96 raw values per lane spill at 2 waves per SIMD)
 #endif
+#ifndef NIC_HOIST_3D
+#define NIC_HOIST_3D 0
+#endif
 #ifndef NIC_HOIST_SPLIT
 #define NIC_HOIST_SPLIT 3
 #endif
@@ -858,7 +861,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // training: the 2D kernels have the registers for a cell's raw values since the build keeps MFMA results out of the
         // accumulator file where vector code consumes them: G0 (24 values) -1.8 % split, -1 % fp32; G0 + G1 (48) another -1.8 % in the
         // split kernel although 9 values spill (the fp32 kernel with both: the compiler gives up); 3D: none
-        constexpr int HOIST_TRAIN = NIC_HOIST_TRAIN >= 0 ? NIC_HOIST_TRAIN : (L::DIM == 2 ? (SPLIT ? NIC_HOIST_SPLIT : 1) : 0);
+        constexpr int HOIST_TRAIN = NIC_HOIST_TRAIN >= 0 ? NIC_HOIST_TRAIN : (L::DIM == 2 ? (SPLIT ? NIC_HOIST_SPLIT : 1) : NIC_HOIST_3D);
         constexpr bool HG0 = SRC == SRC_ENCODE && ((TRAIN ? HOIST_TRAIN : HOIST_INFER) & 1) != 0;
         constexpr bool HG1 = SRC == SRC_ENCODE && ((TRAIN ? HOIST_TRAIN : HOIST_INFER) & 2) != 0;
         CellRaw<L> raw;
