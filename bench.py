@@ -3,24 +3,32 @@
 on BASELINE.json's configs[1]: a 3840 x 2160 RGB fit, dense G0/G1 grid pair (reference semantics, no-mip),
 3 x Linear(64) decoder, in-kernel Threefry noise - every pixel of the image once per step.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-N > 1 is weak scaling (8.29 Mpx per rank and step).  Default --shard stripes: rank r owns a stripe of the image's second axis (a
-contiguous block of grid node rows) and takes its N passes per step from it - the same sample multiset as N replicas each covering
-the image once, but the step exchanges only the loss, the decoder gradients and one boundary node row per neighbour pair (0.3 MB at
-N = 8) instead of the dense grid gradients (31 MB, --shard replicated); the full grids are assembled once after the timed region.
+N > 1: when no rank environment is present this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a CHILD (before anything touches the GPU), relays its output and exits with its code; under torch.distributed.run (the driver's
+own launch) it is one rank and insists on WORLD_SIZE == --gpus.  N > 1 is weak scaling (8.29 Mpx per rank and step).  Default
+--shard stripes: rank r owns a stripe of the image's second axis (a contiguous block of grid node rows) and takes its N passes per
+step from it - the same sample multiset as N replicas each covering the image once, but the step exchanges only the loss, the decoder
+gradients and one boundary node row per neighbour pair (0.3 MB at N = 8) instead of the dense grid gradients (31 MB, --shard
+replicated); the full grids are assembled once after the timed region.
 
-Prints ONE JSON line on rank 0 (see the driver contract); adds `roofline` (dominant kernel = fused_kernel, timed with HIP
-events on its launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded
-strip of the same workload).  --precision split (default): the 2D training default, every matrix product as hi + lo bf16 pairs on
-the bf16 matrix pipe with fp32 accumulation (gradients within 5e-6 of the fp32 kernel; parity-tested against the CPU oracle at the
-fp32 kernel's tolerances); --precision f32: v_mfma_f32_32x32x2_f32 throughout.
+Prints ONE JSON line on rank 0 (see the driver contract).  `value` comes from the K timed steps alone.  Beside it:
+  roofline      dominant kernel (the fused training kernel of --precision), HIP events on its launch stream: `kernel_ms` = mean over
+                the K timed steps (what `achieved` uses); `stats` = median / p10 / p90 over a separate leg of >= 100 launches run
+                after the timed region (the K = 20 of the driver's default is 45 ms - too short for percentiles)
+  roofline_f32  (or roofline_split with --precision f32) the other arithmetic mode, measured in the same run on the same inputs
+  cpu_baseline  N = 1: the CPU oracle on a bounded strip of the same workload at the fastest thread count found on the box
+--precision split (default): the 2D training default, every matrix product as hi + lo bf16 pairs on the bf16 matrix pipe with fp32
+accumulation (gradients within 5e-6 of the fp32 kernel; parity-tested against the CPU oracle at the fp32 kernel's tolerances, at
+this size, with these flags: tests/test_gpu_parity.py::test_full_size_4k_properties); --precision f32: v_mfma_f32_32x32x2_f32.
 """
 import argparse
-import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,6 +47,8 @@ BYTES_PER_SAMPLE = 8 * 12 * 4 + 2 * 8 * 12 * 4 + 3 * 4            # SURVEY 8d, f
 PEAK_FP32_MATRIX_TFLOPS = 157.3                                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_TFLOPS = 2500.0                                        # dense bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+KERNEL_NAME = {"split": "fused training kernel, Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, PREC_SPLIT",
+               "f32": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_F32>"}
 
 
 def synthetic_target(device):
@@ -55,26 +65,93 @@ def synthetic_target(device):
     return img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(device), img
 
 
-def cpu_baseline(img, steps=3):
+def cpu_baseline(img, steps=5, budget_s=30.0):
     """the CPU oracle (certified against the reference by tests/test_oracle_golden.py) on a bounded strip of the workload:
-    the reference's op sequence - gathers, blend, PE, cat, rand_like noise, 3 Linear + GELU, MSE, autograd backward."""
+    the reference's op sequence - gathers, blend, PE, cat, rand_like noise, 3 Linear + GELU, MSE, autograd backward.  Eager torch
+    oversubscribes badly on many-core hosts (128 threads gave 0.19 Mpix/s where 8 cores of the survey box gave 0.4), so the
+    thread count is probed first (one step each on a quarter strip) and the `steps` timed steps run at the fastest one."""
     from oracle import nic_oracle as O
-    strip = 256
     g = torch.Generator().manual_seed(0)
     fp, _ = O.create_pyramid((H // 4, W // 4), 12, 8, dim=2, no_mip=True, generator=g)
     mlp = O.init_mlp(CIN, HID, generator=g)
-    tgt = img[:, :, :strip].permute(1, 2, 0).reshape(-1, 3).contiguous()
-    n = H * strip
-    times = []
-    for _ in range(steps):
+
+    def one(strip):
+        tgt = img[:, :, :strip].permute(1, 2, 0).reshape(-1, 3).contiguous()
+        n = H * strip
         t0 = time.perf_counter()
-        x_noise_shape = (n, CIN)
-        noise = (torch.rand(*x_noise_shape) - 0.5) / 256
+        noise = (torch.rand(n, CIN) - 0.5) / 256
         O.forward_backward(fp[0], fp[1], mlp, [(0, 0)], (H, strip), 0.25, 0, tgt, noise, 6)
-        times.append(time.perf_counter() - t0)
+        return n, time.perf_counter() - t0
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t_start = time.perf_counter()
+    cands = sorted({c for c in (4, 8, 16, 32, 64, avail) if 1 <= c <= avail})
+    probe = {}
+    one(64)                                                            # page in, allocator warm-up
+    for c in cands:
+        torch.set_num_threads(c)
+        n, dt = one(64)
+        probe[c] = n / dt
+        if time.perf_counter() - t_start > budget_s / 3:
+            break
+    best = max(probe, key=probe.get)
+    torch.set_num_threads(best)
+    strip, times = 256, []
+    for _ in range(steps):
+        n, dt = one(strip)
+        times.append(dt)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 3:
+            break
     t = float(np.median(times))
-    return {"value": round(n / t / 1e6, 4), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{H}x{strip} strip of the 4K workload ({n} px) per step, median of {steps} steps of fwd+bwd (eager torch on host cores)"}
+    return {"value": round(n / t / 1e6, 4), "unit": "Mpixels/s", "cores": best, "kind": "port",
+            "threads_probed_mpix_s": {str(k): round(v / 1e6, 4) for k, v in probe.items()}, "host_cores_available": avail,
+            "p10_p90_mpix_s": [round(n / float(np.percentile(times, 90)) / 1e6, 4), round(n / float(np.percentile(times, 10)) / 1e6, 4)],
+            "sample": f"{H}x{strip} strip of the 4K workload ({n} px) per step, median of {len(times)} steps of fwd+bwd "
+                      f"(eager torch, {best} threads = the fastest of {sorted(probe)} probed on this host)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """--gpus N without a rank environment: become the launcher.  Nothing in this process has touched the GPU (no torch.cuda call
+    so far), the ranks are CHILD processes, and their exit code is ours."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC for RCCL on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def pct(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    return {"n": int(xs.size), "median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4),
+            "p90": round(float(np.percentile(xs, 90)), 4), "min": round(float(xs.min()), 4), "mean": round(float(xs.mean()), 4)}
+
+
+def roofline_record(precision, kern_ms, n_launch, traffic, stats=None):
+    """SURVEY 8d figures x the samples one launch processes / the kernel's launch duration"""
+    flops = FLOP_PER_SAMPLE * n_launch / (kern_ms * 1e-3) / 1e12
+    gbs = BYTES_PER_SAMPLE * n_launch / (kern_ms * 1e-3) / 1e9
+    common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,
+              "samples_per_launch": n_launch, "kernel": KERNEL_NAME[precision]}
+    if stats is not None:
+        common["stats"] = stats
+    hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    if precision == "f32":
+        # fp32: the matrix pipe is the tighter roofline (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s vs HBM 8 TB/s / 1 164 B = 6.9 Gpx/s)
+        return {"bound": "mfma", "achieved": round(flops, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / PEAK_FP32_MATRIX_TFLOPS, 4), **common, "hbm_algorithmic": hbm}
+    # split bf16: three bf16 MFMAs per product -> matrix ceiling 2 500 / (3 x 53 760) = 15.5 Gpx/s; the algorithmic-HBM ceiling
+    # (6.9 Gpx/s) is the tighter one (SURVEY 8d), so it is the reported bound; the matrix-pipe figures ride beside it
+    return {"bound": "hbm", **hbm, **common,
+            "mfma_bf16": {"achieved_executed": round(3 * flops, 1), "achieved_algorithmic": round(flops, 2), "peak": PEAK_BF16_TFLOPS,
+                          "unit": "TFLOP/s", "frac_executed": round(3 * flops / PEAK_BF16_TFLOPS, 4)}}
 
 
 def main():
@@ -83,6 +160,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stat-launches", type=int, default=120, help="launches of the post-run statistics leg (median / p10 / p90 of the kernel time); 0: skip")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed kernel launches before the W warm-up steps (clock ramp)")
     ap.add_argument("--precision", choices=["split", "f32"], default="split",
                     help="split: every matrix product of the step as hi + lo bf16 pairs on the bf16 matrix pipe, fp32 accumulate (gradients "
                          "within 5e-6 of the fp32 kernel; the product's default for 2D training); f32: v_mfma_f32_32x32x2_f32 throughout")
@@ -96,16 +175,36 @@ def main():
                          "image once per step and the whole gradient bucket (31 MB) is all-reduced")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="plumbing check of the N-rank launch (tests, no GPU): ranks rendezvous over gloo, sum their ranks, rank 0 prints a JSON line")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rank_sum": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         backend = os.environ.get("NIC_DIST_BACKEND", "nccl")         # "gloo": rehearsal of the N > 1 path on a box with one GPU
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        assert dist.get_world_size() == args.gpus
 
     from neural_image_compression_v2_amd import _lib, fp_def, fused
     from neural_image_compression_v2_amd.distributed import all_reduce_flat, assemble_stripes, plan_stripes, stripe_exchange
@@ -148,13 +247,15 @@ def main():
     stream = _lib.stream_ptr(dev)
     adam_tab = (_lib.NicAdamTensor * len(tensors))()
 
+    def geometry(i, precision):
+        return fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, passes=passes,
+                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
+                                  sample_base=base_mine, loss_scale=1.0 / (3.0 * n_global),
+                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell
+                                  split_bf16=precision == "split")
+
     def step(i, events=None):
-        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, passes=passes,
-                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
-                                 sample_base=base_mine, loss_scale=1.0 / (3.0 * n_global),
-                                 flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell
-                                 split_bf16=args.precision == "split")
-        out = fused.fused_forward_backward(geo, g0, g1, org, params, target, flat=flat, events=events)
+        out = fused.fused_forward_backward(geometry(i, args.precision), g0, g1, org, params, target, flat=flat, events=events)
         if world > 1 and stripes:
             stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)   # RCCL sum of [loss | decoder grads | boundary rows]
         elif stripes:                                                 # --virtual-world: the pack / unpack launches without the collective
@@ -165,10 +266,23 @@ def main():
         grads = out.grad_mlp + [out.grad_g0, out.grad_g1]
         for k, (p, g, m, v) in enumerate(zip(tensors, grads, m_state, v_state)):
             lo, hi = (q_lo, 0.5) if k >= 6 else (1.0, -1.0)           # fp_quantize_clamp on the grids only
-            adam_tab[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), i + 1, lrs[k] * cos, lo, hi, 0)
+            adam_tab[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), i + 1, lrs[k] * cos, lo, hi)
         _lib.check(lib.nic_adam_multi(adam_tab, len(tensors), 0.9, 0.999, 1e-8, stream), "nic_adam_multi")   # Adam + clamp: one launch
         return out
 
+    def kernel_only_leg(precision, launches):
+        """per-launch HIP-event times of the fused kernel alone (no optimiser: the parameters stay put), same inputs and flags"""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for j in range(launches):
+            fused.fused_forward_backward(geometry(total_steps + j, precision), g0, g1, org, params, target, flat=flat, events=evs[j])
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in evs]
+
+    # untimed: bring the clocks up before the W warm-up steps (a 45 ms timed region right after an idle start has no ramp margin)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        fused.fused_forward_backward(geometry(0, args.precision), g0, g1, org, params, target, flat=flat)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -190,7 +304,8 @@ def main():
     loss = float(out.loss)
     if world > 1 and stripes:
         assemble_stripes(plan, g0, g1)                                # once, outside the timed region: the full grids on every rank
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))       # fused kernel (+ its ~10 us partial reduction)
+    timed_kernel_ms = [a.elapsed_time(b) for a, b in ev]               # fused kernel (+ its ~10 us partial reduction)
+    kern_ms = float(np.mean(timed_kernel_ms))
     # the metric's "+ PSNR" (outside the timed region): decode the whole image with the current parameters, PSNR with peak 2^8
     # against the synthetic target (utils.py:117-130) - after warmup + steps optimiser steps from a random initialisation
     from neural_image_compression_v2_amd import models, utils
@@ -199,6 +314,10 @@ def main():
     rec = fused.fused_forward(dgeo, g0, g1, torch.zeros(1, 2, dtype=torch.int32, device=dev), params)
     ref_img = img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(dev)
     psnr = float(utils.calculate_psnr(models.quantize_to_bit(rec, 8), models.quantize_to_bit(ref_img, 8)))
+    # statistics + the other arithmetic mode, after the timed region (every rank runs them: same work everywhere, no collectives)
+    other = "f32" if args.precision == "split" else "split"
+    stat_main = kernel_only_leg(args.precision, args.stat_launches) if args.stat_launches > 0 else None
+    stat_other = kernel_only_leg(other, max(args.stat_launches // 2, 10)) if args.stat_launches > 0 else None
 
     if rank == 0:
         mpix = n_local * world * args.steps / elapsed / 1e6
@@ -209,8 +328,6 @@ def main():
                    + (" (virtual: one process, no collectives)" if world == 1 else ""))
         else:
             par = f"dp{world} (sample-sharded, replicated parameters" + (f", {4 * total} B all-reduced per step)" if world > 1 else ")")
-        flops = FLOP_PER_SAMPLE * n_mine / (kern_ms * 1e-3) / 1e12
-        gbs = BYTES_PER_SAMPLE * n_mine / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")            # HBM bytes per launch from the rocprofv3 --pmc passes, if collected
         if os.path.exists(tp):
@@ -229,21 +346,12 @@ def main():
                        "pixels_per_step_per_gpu": n_local, "parallelism": par,
                        "final_loss": round(loss, 6), "psnr_db_after_these_steps": round(psnr, 3)},
         }
-        common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,
-                  "samples_per_launch": n_mine}
-        hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
-        if args.precision == "f32":
-            # fp32: the matrix pipe is the tighter roofline (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s vs HBM 8 TB/s / 1 164 B = 6.9 Gpx/s)
-            res["roofline"] = {"bound": "mfma", "achieved": round(flops, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(flops / PEAK_FP32_MATRIX_TFLOPS, 4), **common,
-                               "kernel": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_F32>", "hbm_algorithmic": hbm}
-        else:
-            # split bf16: three bf16 MFMAs per product -> matrix ceiling 2 500 / (3 x 53 760) = 15.5 Gpx/s; the algorithmic-HBM ceiling
-            # (6.9 Gpx/s) is the tighter one, so it is the reported bound; the matrix-pipe figures ride beside it
-            res["roofline"] = {"bound": "hbm", **hbm, **common,
-                               "kernel": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_SPLIT>",
-                               "mfma_bf16": {"achieved_executed": round(3 * flops, 1), "achieved_algorithmic": round(flops, 2),
-                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac_executed": round(3 * flops / PEAK_BF16_TFLOPS, 4)}}
+        res["roofline"] = roofline_record(args.precision, kern_ms, n_mine, traffic,
+                                          {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})})
+        if stat_other:
+            # the other arithmetic mode on the same inputs in the same run: its median launch time carries the record
+            res["roofline_" + other] = roofline_record(other, float(np.median(stat_other)), n_mine, None, {"stat_leg": pct(stat_other)})
+            res["roofline_" + other]["mpix_s_kernel_only"] = round(n_mine / float(np.median(stat_other)) / 1e3, 1)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(img)
         print(json.dumps(res), flush=True)

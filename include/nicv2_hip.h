@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 2
+#define NIC_ABI_VERSION 3
 
 enum {
     NIC_OK = 0,
@@ -224,9 +224,11 @@ int nic_psnr(const float *a, const float *b, int64_t n, int num_bits, float *out
 
 /* ---- fused Adam step + in-place clamp for one parameter tensor (image_compression.py:266-269, 361-365):
  *      torch.optim.Adam semantics (no weight decay, no amsgrad), bias-corrected with step count `step` (1-based).
- *      clamp_lo > clamp_hi disables the clamp. */
-int nic_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
-                  float beta1, float beta2, float eps, int64_t step, float clamp_lo, float clamp_hi, void *stream);
+ *      clamp_lo > clamp_hi disables the clamp.  The hyper-parameters are doubles because torch's are Python floats: the library
+ *      forms (float)(1 - beta), (float)(lr / bias_correction1) exactly as torch does (1.0f - 0.999f != 0.001f).  The clamp keeps
+ *      NaN (torch.clamp_ propagates it; a diverged grid must not be silently reset to clamp_lo). */
+int nic_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, int64_t step, float clamp_lo, float clamp_hi, void *stream);
 
 /* ---- the whole optimiser step in ONE launch: Adam for every listed tensor - grids at lr 0.01, decoder
  *      at lr 0.005, each already scaled by the caller's CosineAnnealingLR factor - with the fp_quantize_clamp of the grids
@@ -241,11 +243,10 @@ typedef struct nic_adam_tensor {
     float *exp_avg_sq;
     int64_t n;
     int64_t step;            /* 1-based step count of THIS tensor */
-    float lr;
+    double lr;
     float clamp_lo, clamp_hi; /* clamp_lo > clamp_hi: no clamp */
-    int32_t reserved;
 } nic_adam_tensor;
-int nic_adam_multi(const nic_adam_tensor *tensors, int count, float beta1, float beta2, float eps, void *stream);
+int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
 
 #ifdef __cplusplus
 }

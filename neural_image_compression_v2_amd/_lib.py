@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 2
+NIC_ABI_VERSION = 3
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -51,8 +51,8 @@ NIC_ADAM_MAX_TENSORS = 32
 class NicAdamTensor(ctypes.Structure):
     """struct nic_adam_tensor (include/nicv2_hip.h)."""
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
-                ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_float), ("clamp_lo", ctypes.c_float),
-                ("clamp_hi", ctypes.c_float), ("reserved", ctypes.c_int32)]
+                ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("clamp_lo", ctypes.c_float),
+                ("clamp_hi", ctypes.c_float)]
 
 
 class NicTargetImage(ctypes.Structure):
@@ -61,7 +61,7 @@ class NicTargetImage(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
-_P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_P, _I, _L, _F, _SZ, _DBL = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_double
 _D = ctypes.POINTER(NicPathDesc)
 _M = ctypes.POINTER(NicMlp)
 _G = ctypes.POINTER(NicMlpGrads)
@@ -90,9 +90,9 @@ SIGNATURES = {
     "nic_save4fp_u8": (_I, [_P, _P, _L, _I, _P]),
     "nic_load4fp_u8": (_I, [_P, _P, _L, _I, _P]),
     "nic_psnr": (_I, [_P, _P, _L, _I, _P, _P, _SZ, _P]),
-    "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _L, _F, _F, _P]),
+    "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _DBL, _DBL, _DBL, _DBL, _L, _F, _F, _P]),
     "nic_gather_corners": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P]),
-    "nic_adam_multi": (_I, [ctypes.POINTER(NicAdamTensor), _I, _F, _F, _F, _P]),
+    "nic_adam_multi": (_I, [ctypes.POINTER(NicAdamTensor), _I, _DBL, _DBL, _DBL, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -204,9 +204,11 @@ __global__ void __launch_bounds__(256) quantize_kernel(const float* src, float* 
         dst[i] = OP == Q_QUANT ? q : __fmul_rn(q, scale);
     }
 }
+// torch.clamp_ (fp_quantize_clamp, fp_def.py:227-232) propagates NaN; fminf / fmaxf would map a diverged parameter to `lo`
+__device__ __forceinline__ float clamp_keep_nan(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
 __global__ void __launch_bounds__(256) clamp_kernel(float* x, int64_t n, float lo, float hi) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        x[i] = fminf(fmaxf(x[i], lo), hi);
+        x[i] = clamp_keep_nan(x[i], lo, hi);
 }
 __global__ void __launch_bounds__(256) save4fp_kernel(const float* src, uint8_t* dst, int64_t n, float scale, float bias) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -259,18 +261,20 @@ __global__ void __launch_bounds__(256) psnr_final_kernel(const double* part, int
 // torch.optim.Adam single-tensor semantics (default: no weight decay, no amsgrad, eps outside sqrt after
 // bias correction) + the fp_quantize_clamp that follows it (image_compression.py:266-269).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                                                   float b2, float eps, float bc1, float bc2_sqrt, float lo, float hi) {
-    const float step_size = lr / bc1;
+// The scalars are formed on the host in double and cast once, like torch does with its Python-float hyper-parameters:
+// omb1 = (float)(1 - beta1), omb2 = (float)(1 - beta2), step_size = (float)(lr / bias_correction1), bc2_sqrt = (float)sqrt(bias_correction2)
+// (1.0f - 0.999f in fp32 is 9.99987e-4, not 0.001f: exp_avg_sq would drift 1.3e-5 low).
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float b2,
+                                                   float omb1, float omb2, float eps, float bc2_sqrt, float lo, float hi) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        const float mi = m[i] + (gi - m[i]) * omb1;                    // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + omb2 * gi * gi;                  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         float x = p[i] - step_size * (mi / denom);
-        if (lo <= hi) x = fminf(fmaxf(x, lo), hi);
+        if (lo <= hi) x = clamp_keep_nan(x, lo, hi);
         p[i] = x;
     }
 }
@@ -286,15 +290,15 @@ struct AdamEntry {
 struct AdamTable {
     AdamEntry e[NIC_ADAM_MAX_TENSORS];
     int count;
-    float b1, b2, eps;
+    float b2, omb1, omb2, eps;
 };
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamTable& t, float step_size, float bc2_sqrt,
                                          float lo, float hi) {
-    m = m + (g - m) * (1.0f - b1);
-    v = v * b2 + (1.0f - b2) * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    m = m + (g - m) * t.omb1;
+    v = v * t.b2 + t.omb2 * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + t.eps;
     float x = p - step_size * (m / denom);
-    if (lo <= hi) x = fminf(fmaxf(x, lo), hi);
+    if (lo <= hi) x = clamp_keep_nan(x, lo, hi);
     p = x;
 }
 constexpr int kAdamChunk = 4096;
@@ -312,15 +316,15 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
         for (int i = threadIdx.x; i < n4; i += 256) {
             float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
             const float4 gg = reinterpret_cast<const float4*>(g)[i];
-            adam_one(pp.x, gg.x, mm.x, vv.x, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.y, gg.y, mm.y, vv.y, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.z, gg.z, mm.z, vv.z, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.w, gg.w, mm.w, vv.w, t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.x, gg.x, mm.x, vv.x, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.y, gg.y, mm.y, vv.y, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.z, gg.z, mm.z, vv.z, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            adam_one(pp.w, gg.w, mm.w, vv.w, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
             reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
         }
-        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
     } else {
-        for (int i = threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t.b1, t.b2, t.eps, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+        for (int i = threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
     }
 }
 
@@ -509,23 +513,23 @@ int nic_psnr(const float* a, const float* b, int64_t n, int num_bits, float* out
     return (int)hipGetLastError();
 }
 
-int nic_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int64_t step, float clamp_lo, float clamp_hi, void* stream) {
+int nic_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int64_t step, float clamp_lo, float clamp_hi, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq) return NIC_E_NULL;
     if (n <= 0 || step < 1) return n == 0 ? NIC_OK : NIC_E_ARG;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, (float)bc1, (float)sqrt(bc2), clamp_lo, clamp_hi);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       (float)(lr / bc1), (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), clamp_lo, clamp_hi);
     return (int)hipGetLastError();
 }
 
-int nic_adam_multi(const nic_adam_tensor* tensors, int count, float beta1, float beta2, float eps, void* stream) {
+int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, double beta2, double eps, void* stream) {
     if (count == 0) return NIC_OK;
     if (!tensors) return NIC_E_NULL;
     if (count < 0 || count > NIC_ADAM_MAX_TENSORS) return NIC_E_ARG;
     AdamTable t;
-    t.b1 = beta1; t.b2 = beta2; t.eps = eps;
+    t.b2 = (float)beta2; t.omb1 = (float)(1.0 - beta1); t.omb2 = (float)(1.0 - beta2); t.eps = (float)eps;
     int nt = 0;
     int64_t blocks = 0;
     for (int i = 0; i < count; ++i) {
@@ -533,11 +537,11 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, float beta1, float
         if (a.n == 0) continue;
         if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) return NIC_E_NULL;
         if (a.n < 0 || a.step < 1) return NIC_E_ARG;
-        const double bc1 = 1.0 - pow((double)beta1, (double)a.step);
-        const double bc2 = 1.0 - pow((double)beta2, (double)a.step);
+        const double bc1 = 1.0 - pow(beta1, (double)a.step);
+        const double bc2 = 1.0 - pow(beta2, (double)a.step);
         AdamEntry& e = t.e[nt++];
         e.p = a.param; e.g = a.grad; e.m = a.exp_avg; e.v = a.exp_avg_sq; e.n = a.n;
-        e.step_size = a.lr / (float)bc1;          // same roundings as nic_adam_step: (float) bias corrections, fp32 division in-kernel there
+        e.step_size = (float)(a.lr / bc1);        // formed in double like torch's Python-float step_size, cast once
         e.bc2_sqrt = (float)sqrt(bc2);
         e.lo = a.clamp_lo; e.hi = a.clamp_hi;
         e.first_block = (int)blocks;

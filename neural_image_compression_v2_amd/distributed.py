@@ -3,7 +3,7 @@
 The reference is single-device; its step is ``NUM_CROPS`` independent crops whose losses are averaged
 (image_compression.py:233-265), so the path shards by crop: every rank holds the full grids + decoder, runs the
 fused kernel on its crops with ``loss_scale = 1 / (3 * N_global)`` and ``sample_base`` = the global id of its first
-sample (so the Philox noise does not depend on the world size), and ONE all-reduce(sum) of the flat buffer
+sample (so the in-kernel Threefry-4x32-12 noise does not depend on the world size), and ONE all-reduce(sum) of the flat buffer
 ``[loss | decoder grads | G0 grad | G1 grad]`` (fused.grad_bucket_layout) gives every rank the gradients of the
 global batch.  One process per GPU; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests.
 
@@ -71,6 +71,11 @@ def data_parallel_step(step_fn: Callable, geo, g0, g1, origins_global, params, t
     target         : [N_global, 3] (sliced here) or, with target_is_local, this rank's [N_local, 3]
     returns the StepOutput of step_fn whose .flat now holds global sums (loss = global mean)
     """
+    if int(getattr(geo, "passes", 1)) != 1:
+        # sample ids are (crop * passes + pass) * n_per_crop + ...: the crop shards of this function assume one pass per crop
+        # (n_global, sample_base and the target slice would all be off by the factor `passes`); repeated passes belong to the
+        # stripe-sharded step (StripePlan), which takes them from one crop
+        raise ValueError("data_parallel_step shards crops with passes == 1; use the stripe-sharded step for repeated passes")
     plan = plan or plan_shard(geo.num_crops, geo.n_per_crop)
     if plan.crop_count == 0:
         raise ValueError("more ranks than crops: give every rank at least one crop")

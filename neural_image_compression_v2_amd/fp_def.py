@@ -54,7 +54,8 @@ def _create(base, dim, channels, num_bits, device, dtype, no_mip):
     pyramid = []
     for i in range(levels * 2):
         shape = [channels] + [b // (2 ** i) + 1 for b in reversed(base)]     # tensor axes (z,) y, x
-        g = torch.empty(*shape, device=device, dtype=torch.float32).uniform_(lo, hi).requires_grad_(True)
+        # the reference's own expression (fp_def.py:54,76): same RNG stream and rounding as it for a given seed / device
+        g = ((hi - lo) * torch.rand(*shape, device=device, dtype=torch.float32) + lo).requires_grad_(True)
         pyramid.append(g)
     return pyramid, levels
 
@@ -78,9 +79,10 @@ def _gather(grid, corner_set, xi, yi, zi=None):
     n = idx[0].numel()
     K = 8 if corner_set == 1 else 4
     out = torch.empty(K, C, n, dtype=torch.float32, device=g.device)
-    _lib.check(_lib.load().nic_gather_corners(_lib.ptr(g), C, nx, ny, nz, _lib.ptr(idx[0]), _lib.ptr(idx[1]),
-                                              _lib.ptr(idx[2] if zi is not None else None), n, corner_set, _lib.ptr(out),
-                                              _lib.stream_ptr(g.device)), "nic_gather_corners")
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.load().nic_gather_corners(_lib.ptr(g), C, nx, ny, nz, _lib.ptr(idx[0]), _lib.ptr(idx[1]),
+                                                  _lib.ptr(idx[2] if zi is not None else None), n, corner_set, _lib.ptr(out),
+                                                  _lib.stream_ptr(g.device)), "nic_gather_corners")
     return tuple(out[k] for k in range(K))
 
 
@@ -150,7 +152,8 @@ def fp_quantize_clamp(fp, fl, num_bits):
             t = _lib.require_cuda_f32(g, "grid")
             if t.data_ptr() != g.data_ptr():
                 raise RuntimeError("grids must be contiguous")
-            _lib.check(lib.nic_clamp(_lib.ptr(t), t.numel(), lo, hi, _lib.stream_ptr(t.device)), "nic_clamp")
+            with torch.cuda.device(t.device):
+                _lib.check(lib.nic_clamp(_lib.ptr(t), t.numel(), lo, hi, _lib.stream_ptr(t.device)), "nic_clamp")
 
 
 def fp_quantize(fp, fl, num_bits):

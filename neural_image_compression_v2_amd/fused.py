@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import dataclasses
+import functools
 import math
 import os
 from dataclasses import dataclass, field, replace
@@ -17,6 +18,19 @@ import torch
 from . import _lib
 from ._lib import (NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED, NIC_NOISE_NONE, NIC_NOISE_KERNEL,
                    NIC_NOISE_TENSOR, NIC_PE_SINUSOIDAL, NIC_PE_TRIANGULAR)
+
+
+def _on_tensor_device(fn):
+    """Runs ``fn`` with the device of its first HIP tensor argument current: the kernels launch on that device's stream, and a
+    launch on a stream of a device that is not the current one fails (multi-GPU processes, config 5's per-GPU fits)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapper
 
 
 def g1_weights_enabled(step_number) -> bool:
@@ -205,6 +219,7 @@ def check_mlp(params: Sequence[torch.Tensor], cin: int, hidden: int) -> List[tor
 # plain calls
 # ------------------------------------------------------------------------------------------------------
 
+@_on_tensor_device
 def encode(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -> torch.Tensor:
     """[N, Cin] decoder input (create_decoder_input_* / finally_decode_input_*, image_compression.py:71-211)"""
     g0 = _lib.require_cuda_f32(g0.detach(), "G0")
@@ -218,6 +233,7 @@ def encode(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -> torc
     return out
 
 
+@_on_tensor_device
 def encode_split(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -> torch.Tensor:
     """[K0*C + K1*C + P*D, n] rows for ONE crop (create_g0_g1*, fp_def.py:115-223)"""
     g0 = _lib.require_cuda_f32(g0.detach(), "G0")
@@ -234,6 +250,7 @@ def encode_split(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -
     return out
 
 
+@_on_tensor_device
 def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[N, 3]: encode (+ noise) + decoder in one kernel (decode_image's inner step, image_compression.py:313-345)"""
     g0 = _lib.require_cuda_f32(g0.detach(), "G0")
@@ -254,6 +271,7 @@ def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torc
     return y
 
 
+@_on_tensor_device
 def fused_forward_u8(geo: PathGeometry, g0_u8, g1_u8, coord, params, out: str = "float"):
     """Decode from the STORED grids (the uint8 tensors ``fp_savable`` wrote, fp_def.py:250-255) without materialising fp32
     grids: dequantisation happens in the gather, bit-identical to ``fp_load`` + :func:`fused_forward`.
@@ -335,6 +353,7 @@ def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor):
     return offs, sizes, o
 
 
+@_on_tensor_device
 def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: torch.Tensor,
                            noise: Optional[torch.Tensor] = None, want_y: bool = False,
                            flat: Optional[torch.Tensor] = None, events=None) -> StepOutput:
@@ -412,6 +431,7 @@ class FusedGridMLP(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dy):
         g0, g1, *params = ctx.saved_tensors
         geo = ctx.geo
@@ -458,6 +478,7 @@ class EncodeFunction(torch.autograd.Function):
         return encode(geo, g0, g1, org)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dx):
         geo = ctx.geo
         dx = _lib.require_cuda_f32(dx, "dx")
@@ -481,6 +502,7 @@ class DecoderFunction(torch.autograd.Function):
     """ColorDecoder.forward on an explicit [n, Cin] input (image_compression.py:66-68) and its backward."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, x, w1, b1, w2, b2, w3, b3):
         params = check_mlp([w1, b1, w2, b2, w3, b3], x.shape[1], w2.shape[0])
         xc = _lib.require_cuda_f32(x, "x")
@@ -493,6 +515,7 @@ class DecoderFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dy):
         x, *params = ctx.saved_tensors
         dy = _lib.require_cuda_f32(dy, "dy")

@@ -19,7 +19,8 @@ def _q_range(num_bits):
 def _run(fn_name, src: torch.Tensor, num_bits: int, out_dtype=torch.float32):
     s = _lib.require_cuda_f32(src.detach(), "tensor")
     dst = torch.empty(s.shape, dtype=out_dtype, device=s.device)
-    _lib.check(getattr(_lib.load(), fn_name)(_lib.ptr(s), _lib.ptr(dst), s.numel(), int(num_bits), _lib.stream_ptr(s.device)), fn_name)
+    with torch.cuda.device(s.device):
+        _lib.check(getattr(_lib.load(), fn_name)(_lib.ptr(s), _lib.ptr(dst), s.numel(), int(num_bits), _lib.stream_ptr(s.device)), fn_name)
     return dst
 
 
@@ -56,7 +57,8 @@ def quantize_clamp(tensor, num_bits=8):
     """clamp to [q_min, 1/2] (models.py:48-51); returns a new tensor"""
     lo, hi = _q_range(num_bits)
     out = _lib.require_cuda_f32(tensor.detach(), "tensor").clone()
-    _lib.check(_lib.load().nic_clamp(_lib.ptr(out), out.numel(), lo, hi, _lib.stream_ptr(out.device)), "nic_clamp")
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().nic_clamp(_lib.ptr(out), out.numel(), lo, hi, _lib.stream_ptr(out.device)), "nic_clamp")
     return out
 
 
@@ -80,5 +82,6 @@ def load4fp(tensor, num_bits, dtype=torch.float32):
         raise NotImplementedError("fp32 only")
     t = tensor.contiguous()
     dst = torch.empty(t.shape, dtype=torch.float32, device=t.device)
-    _lib.check(_lib.load().nic_load4fp_u8(_lib.ptr(t), _lib.ptr(dst), t.numel(), int(num_bits), _lib.stream_ptr(t.device)), "nic_load4fp_u8")
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().nic_load4fp_u8(_lib.ptr(t), _lib.ptr(dst), t.numel(), int(num_bits), _lib.stream_ptr(t.device)), "nic_load4fp_u8")
     return dst

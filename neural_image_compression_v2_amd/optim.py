@@ -64,7 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 lo, hi = self._clamp.get(id(p), (1.0, -1.0))
                 entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                  p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi, 0))
+                                                  p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi))
                 device = p.device
         for (b1, b2, eps), entries in batches.items():
             for i in range(0, len(entries), _lib.NIC_ADAM_MAX_TENSORS):

@@ -21,8 +21,9 @@ def _pe(coord, num_channels, mode):
     D, n = c.shape
     out = torch.empty(num_channels * D, n, dtype=torch.float32, device=c.device)
     div = (ctypes.c_float * 8)(*(sinusoidal_div_term(num_channels) + [0.0] * 8)[:8])
-    _lib.check(_lib.load().nic_positional_encoding(_lib.ptr(c), n, D, int(num_channels), mode, div, _lib.ptr(out),
-                                                   _lib.stream_ptr(c.device)), "nic_positional_encoding")
+    with torch.cuda.device(c.device):
+        _lib.check(_lib.load().nic_positional_encoding(_lib.ptr(c), n, D, int(num_channels), mode, div, _lib.ptr(out),
+                                                       _lib.stream_ptr(c.device)), "nic_positional_encoding")
     return out
 
 
@@ -64,8 +65,9 @@ def lut_gather(encodings, coordinates):
         raise RuntimeError("coordinates must be on the HIP device")
     b, L = c.shape
     out = torch.empty(b, lut.shape[0], L, dtype=torch.float32, device=lut.device)
-    _lib.check(_lib.load().nic_lut_gather(_lib.ptr(lut), lut.shape[0], lut.shape[1], _lib.ptr(c), b, L, _lib.ptr(out),
-                                          _lib.stream_ptr(lut.device)), "nic_lut_gather")
+    with torch.cuda.device(lut.device):
+        _lib.check(_lib.load().nic_lut_gather(_lib.ptr(lut), lut.shape[0], lut.shape[1], _lib.ptr(c), b, L, _lib.ptr(out),
+                                              _lib.stream_ptr(lut.device)), "nic_lut_gather")
     return out
 
 
@@ -108,8 +110,9 @@ def calculate_psnr(original, reconstructed, num_bits=8):
         raise ValueError("shape mismatch")
     out = torch.empty(2, dtype=torch.float32, device=a.device)
     ws = _lib.workspace(a.device, 1024 * 8)
-    _lib.check(_lib.load().nic_psnr(_lib.ptr(a), _lib.ptr(b), a.numel(), int(num_bits), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                    _lib.stream_ptr(a.device)), "nic_psnr")
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().nic_psnr(_lib.ptr(a), _lib.ptr(b), a.numel(), int(num_bits), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr(a.device)), "nic_psnr")
     return out[1]
 
 

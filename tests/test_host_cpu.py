@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nicv2_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.nic_abi_version() == 2
+    assert lib.nic_abi_version() == _lib.NIC_ABI_VERSION == 3
     assert lib.nic_error_string(-2).decode().startswith("unsupported")
     assert lib.nic_decoder_input_channels(2, 1, 12, 6) == 73          # var2.py:114-118
     assert lib.nic_decoder_input_channels(3, 3, 12, 6) == 127
@@ -362,3 +362,44 @@ def test_stripe_sharded_step_matches_single_process_gloo():
             for k in ("small", "g0", "g1"):
                 assert res[k] < 1e-6, (r, res)
             assert res["p0"] < 1e-6 and res["p1"] < 1e-6, (r, res)
+
+
+def test_integration_md_binding_matches_the_c_struct():
+    """the ctypes stub printed in INTEGRATION.md is what a maintainer copies: its nic_path_desc must have the size and field
+    offsets of the C struct (a struct 8 bytes short makes check_geometry read garbage)"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class nic_path_desc\(ctypes\.Structure\):.*?\n(    _fields_ = \[.*?\]\n)\n", text, flags=re.S)
+    assert m, "INTEGRATION.md no longer shows the nic_path_desc binding"
+    ns = {"ctypes": ctypes}
+    exec("class nic_path_desc(ctypes.Structure):\n" + m.group(1), ns)
+    doc = ns["nic_path_desc"]
+    from neural_image_compression_v2_amd._lib import NicPathDesc
+    assert [f[0] for f in doc._fields_] == [f[0] for f in NicPathDesc._fields_]
+    prog = ['#include <stdio.h>', f'#include "{HEADER}"', 'int main(){printf("%zu\\n", sizeof(nic_path_desc)); return 0;}']
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(prog))
+        subprocess.run(["gcc", "-std=c11", src, "-o", exe], check=True)
+        size = int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+    assert ctypes.sizeof(doc) == size == ctypes.sizeof(NicPathDesc)
+    for f, _ in doc._fields_:
+        assert getattr(doc, f).offset == getattr(NicPathDesc, f).offset, f
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no rank environment must start two ranks itself (torch.distributed.run as a child process)
+    and relay rank 0's JSON line; a rank whose WORLD_SIZE disagrees with --gpus exits non-zero.  --launch-check keeps the GPU out
+    of it (gloo rendezvous on 127.0.0.1 only)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    rec = json.loads(lines[0])
+    assert rec == {"launch_check": True, "n_gpus": 2, "rank_sum": 1.0}
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r2.stderr
