@@ -102,6 +102,10 @@ typedef struct nic_path_desc {
  * Agreement with the fp32 kernels: outputs ~3e-7, gradients <= 7e-6 relative (the fp32 kernels themselves sit ~1e-6 from the
  * CPU oracle).  The fp32-input MFMA blocks the wave's vector issue, the bf16 one does not. */
 #define NIC_FLAG_SPLIT_BF16 2
+/* With NIC_FLAG_SPLIT_BF16, 2D training: keep the step on the 4-wave x 32-sample kernel (one wave per SIMD) instead of the default
+ * 8-wave x 16-sample kernel (two waves per SIMD; same arithmetic mode, different tiling and summation order).  Kept for
+ * comparison runs and as the second implementation the parity tests hold the default against. */
+#define NIC_FLAG_SPLIT_TILE32 4
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */
 typedef struct nic_mlp {

@@ -21,6 +21,7 @@ NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
 NIC_FLAG_ORIGINS_ALIGNED = 1
 NIC_FLAG_SPLIT_BF16 = 2
+NIC_FLAG_SPLIT_TILE32 = 4
 
 
 class NicPathDesc(ctypes.Structure):

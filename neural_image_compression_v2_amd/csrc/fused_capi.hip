@@ -1,6 +1,8 @@
 // C ABI of the fused encode + decoder kernels (include/nicv2_hip.h): argument checks, launch geometry,
 // workspace bookkeeping.  No allocation, no synchronisation: capture-safe.
 #include "fused_launch.hpp"
+#include "fused_t16.hpp"
+#include <stdlib.h>
 #include <string.h>
 
 using namespace nic;
@@ -27,6 +29,19 @@ int pick_layout(const nic_path_desc* d) {
     return NIC_E_UNSUPPORTED;
 }
 int layout_of_cin(int cin) { return cin == 73 ? 1 : (cin == 127 ? 3 : (cin == 79 ? 4 : NIC_E_UNSUPPORTED)); }
+
+// 2D training steps with split-bf16 products run on the 8-wave / 16-sample kernel (fused_train16.hpp: two waves per SIMD).
+// NIC_T16=0 in the environment keeps them on the 4-wave / 32-sample fused_kernel (A/B timing, and the reference the parity tests
+// compare the new kernel with).
+bool use_t16(int layout, const nic_path_desc* d) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("NIC_T16");
+        enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    return enabled && (layout == 1 || layout == 2) && (d->flags & NIC_FLAG_SPLIT_BF16) != 0 && (d->flags & NIC_FLAG_SPLIT_TILE32) == 0;
+}
+FusedInfo info_t16() { return FusedInfo{0, train16_record_floats(), 16, 1, 1, 73, 8}; }
 
 FusedInfo info_of(int layout) {
     switch (layout) {
@@ -59,10 +74,10 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
     // the kernels address a grid element as (wave-uniform channel-plane base) + (32-bit byte offset of the lane): a G0 channel
-    // plane, and 7 G1 channel planes (the lane-half term of the G1 offsets), must stay below 4 GiB
+    // plane, and 10 G1 channel planes (the lane-quarter term of the G1 offsets), must stay below 4 GiB
     int64_t n0 = 1, n1 = 1;
     for (int a = 0; a < d->dim; ++a) { n0 *= d->g0_nodes[a]; n1 *= d->g1_nodes[a]; }
-    if (n0 >= (int64_t)1 << 30 || 7 * n1 >= (int64_t)1 << 30) return NIC_E_UNSUPPORTED;
+    if (n0 >= (int64_t)1 << 30 || 10 * n1 >= (int64_t)1 << 30) return NIC_E_UNSUPPORTED;
     if (d->log2_step < -8 || d->log2_step > 8) return NIC_E_ARG;
     if (d->g1_weight_mode < 0 || d->g1_weight_mode > 2 || d->noise_mode < 0 || d->noise_mode > 2) return NIC_E_ARG;
     return NIC_OK;
@@ -78,8 +93,8 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 #ifndef NIC_RG_MAX
 #define NIC_RG_MAX 2
 #endif
-void balance_units(FusedParams& p, int per_cu) {
-    const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * 4;
+void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
+    const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
     double best = 0.0;
@@ -90,8 +105,8 @@ void balance_units(FusedParams& p, int per_cu) {
     }
 }
 
-int grid_for(int64_t n_tiles, int per_cu) {
-    int64_t want = (n_tiles + 3) / 4;                 // 4 waves per block, one tile each
+int grid_for(int64_t n_tiles, int per_cu, int waves_per_wg = 4) {
+    int64_t want = (n_tiles + waves_per_wg - 1) / waves_per_wg;                 // one tile per wave
     want = (want + 7) / 8 * 8;
     const int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
     if (want > cap) want = cap;
@@ -135,7 +150,7 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     } else if (rem > 0) {
         p.edge_lw = 0;
         while ((1 << p.edge_lw) < rem) ++p.edge_lw;
-        const int eh = 32 >> p.edge_lw;                                // blocks along y per edge tile
+        const int eh = (fi.tx * fi.ty) >> p.edge_lw;                   // blocks along y per edge tile
         edge_tiles = (int64_t)((by + eh - 1) / eh) * tz;
     }
     p.tiles_y = ty; p.tiles_z = tz;
@@ -181,7 +196,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         if (img->is_u8 && !(img->den > 0.f)) return NIC_E_ARG;
     }
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
-    const FusedInfo fi = info_of(layout);
+    const bool t16 = use_t16(layout, d);
+    const FusedInfo fi = t16 ? info_t16() : info_of(layout);
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise);
     fill_mlp(p, mlp);
@@ -200,12 +216,19 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_rcp = 1.0f / p.timg_den;
     }
     p.partials = (float*)workspace;
-    balance_units(p, 1);
-    const int grid = grid_for(p.n_tiles << p.rg_log2, 1);
-    const int n_rec = grid * 4 / fi.waves_per_rec;
+    const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
+    balance_units(p, 1, wpw);
+    const int grid = grid_for(p.n_tiles << p.rg_log2, 1, wpw);
+    const int n_rec = grid;                                   // one record per workgroup
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    rc = launch(layout, SRC_ENCODE, img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY), p, grid, s);
+    const int mode = img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY);
+    if (t16) {
+        rc = launch_train16(layout, mode, p, grid, s);
+        if (rc) return rc;
+        return launch_reduce16(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
+    }
+    rc = launch(layout, SRC_ENCODE, mode, p, grid, s);
     if (rc) return rc;
     return reduce(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
 }
@@ -220,8 +243,8 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
         const int layout = pick_layout(d);
         if (layout > 0) rec = info_of(layout).rec;
     }
-    const size_t waves = (size_t)(cu_count() / 8 * 8) * 4;
-    const size_t fused = waves * rec * sizeof(float);
+    if (train16_record_floats() > rec) rec = train16_record_floats();
+    const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float);      // one record per workgroup, at most one workgroup per CU
     const size_t psnr = 1024 * sizeof(double);
     return fused > psnr ? fused : psnr;
 }

@@ -1,0 +1,9 @@
+// host interface of the 8-wave / 16-sample 2D training kernels (fused_t16.hip)
+#pragma once
+#include "fused_kernel.hpp"
+
+namespace nic {
+int launch_train16(int layout, int mode, const FusedParams& p, int grid, hipStream_t s);
+int launch_reduce16(int layout, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+int train16_record_floats();
+}  // namespace nic

@@ -1,0 +1,851 @@
+// Two waves per SIMD: the 2D split-bf16 training kernel as 8 waves x 16 samples (fused_train16_kernel<Layout, MODE>).
+//
+// fused_kernel (fused_kernel.hpp) carries 32 samples per wave on 32x32x16 MFMAs and needs ~490 registers: ONE wave per SIMD, which
+// issues a vector instruction every ~5 cycles where the SIMD could execute one every 2.  This kernel halves the
+// tile: a wave owns 16 samples, every chained product runs on v_mfma_f32_16x16x32_bf16 (D: lane l = (sample n = l & 15, quarter
+// g = l >> 4) holds rows 4g .. 4g+3 of a 16-row tile), a workgroup is 8 waves = two per SIMD, <= 256 registers per lane.
+//
+// Layout rules (all checked against the fp32 kernel and the CPU oracle by tests/test_gpu_parity.py):
+//   * quarter g of sample n owns 24 input slots: G0 corner g (12 channels), G1 channels 3g..3g+2 (blended), one zero, PE rows
+//     3g..3g+2, LOD (g = 0) / the constant one that carries b1 (g = 1), zeros.  Slots 8s..8s+7 of the four quarters are the B
+//     operand of k-step s as they stand (k = 8g + j): the internal input row of (slot, g) is rho = 32 (slot >> 3) + 8g + (slot & 7),
+//     the third k-step (slots 16..19) is stored compactly as rho = 64 + 4g + (slot - 16): 80 columns;
+//   * hidden activations: register r of row tile t of quarter g = hidden unit 16t + 4g + r; as the B operand of the next product
+//     the eight registers of tiles 2s, 2s+1 are k-step s, i.e. hidden unit h sits at POSITION pos(h) = 32 (t >> 1) + 8g + 4 (t & 1) + r
+//     of the contraction.  Every LDS image whose columns are hidden units (W2, W3, the a1 / a2 / dZ images) is stored in position
+//     order, so a forward A fragment is ONE ds_read_b128 and a fragment store ONE ds_write_b128;
+//   * transposed products (dA2, dA1, dX) read their A fragments from the same weight images with ds_read_b64_tr_b16;
+//   * weight-gradient products contract over the samples of all 8 waves ([sample][position] bf16 images, hi + lo, of every wave):
+//     dW2 and the first 64 columns of dW1 as 32x32 tiles on v_mfma_f32_32x32x16_bf16, wave w owning tile w & 3 over the samples of
+//     waves 4 (w >> 2) .. + 3 (two partial sums per tile, added by reduce16_kernel); the last 16 columns of dW1 as 16x16 tiles
+//     (wave w: rows 16 (w & 3).., k-steps 2 (w >> 2), + 1); dW3 and db2 per wave over its own samples on 4x4x4 MFMAs.
+//   * everything else - cell-major lanes, per-cell register sums flushed once with fp32 atomics, G1 lane combine, staggered flush
+//     phases, round groups, edge tiles, XCD-aware persistent walk, fixed-order partial reduction - is the scheme of fused_kernel.hpp.
+#pragma once
+#include "fused_kernel.hpp"
+
+#ifndef NIC_T16_HOIST
+#define NIC_T16_HOIST 3       // bit 0: a cell's raw G0 values gathered once per macro-tile, bit 1: G1
+#endif
+
+namespace nic {
+
+struct Lds16 {
+    static constexpr int LD1 = 80, LD2 = 80, LD3 = 80;     // weight images (bf16 elements): 160-byte rows, conflict-free b128 row reads
+    static constexpr int LDZ = 72, LDX = 88;               // wave images: conflict-free fragment stores and 32x32x16 transposed reads
+    static constexpr int KP = 80;                          // compact input columns (rho)
+    static constexpr int OFF_W1 = 0;                       // hi [64][LD1], lo [64][LD1]
+    static constexpr int W1LO = kH * LD1;
+    static constexpr int OFF_W2 = OFF_W1 + 2 * kH * LD1;
+    static constexpr int W2LO = kH * LD2;
+    static constexpr int OFF_W3 = OFF_W2 + 2 * kH * LD2;   // hi [4][LD3] (row 3 = zeros), lo [4][LD3]
+    static constexpr int W3LO = 4 * LD3;
+    static constexpr int OFF_B = OFF_W3 + 2 * 4 * LD3;     // fp32: b2 [64], b3 [4]  (136 bf16 elements, padded to 144)
+    static constexpr int OFF_IMG = OFF_B + 144;
+    // per wave: DZ hi, lo | A1 hi, lo | X hi, lo | D3 hi [4][16], lo
+    static constexpr int DZLO = 16 * LDZ, OFF_A1 = 2 * 16 * LDZ, OFF_X = 4 * 16 * LDZ, XLO = 16 * LDX, OFF_D3 = OFF_X + 2 * 16 * LDX;
+    static constexpr int SPW = OFF_D3 + 128;
+    static constexpr int TOTAL = OFF_IMG + 8 * SPW;         // bf16 elements
+    static_assert(TOTAL * 2 <= 163840, "LDS");
+    static_assert(OFF_IMG % 8 == 0 && SPW % 8 == 0 && OFF_B % 8 == 0, "16-byte alignment");
+    // per-workgroup record of decoder-gradient partials (floats)
+    static constexpr int REC_W2 = 0, REC_W1 = 8 * 1024, REC_TAIL = 16 * 1024, REC_WAVE = REC_TAIL + 8 * 256, REC = REC_WAVE + 8 * 320;
+};
+
+// decoder-input channel of slot sigma of quarter g (image_compression.py:94-96 channel order)
+__host__ __device__ constexpr int slot16_channel(int s, int g) {
+    if (s < 12) return 12 * g + s;                      // G0 corner g, channel s
+    if (s < 15) return 48 + 3 * g + (s - 12);           // G1 channel 3g + ..
+    if (s == 15) return kSlotZero;
+    if (s < 19) return 60 + 3 * g + (s - 16);           // PE row 3g + ..
+    if (s == 19) return g == 0 ? 72 : (g == 1 ? kSlotOne : kSlotZero);
+    return kSlotZero;
+}
+// channel (or kSlotOne / kSlotZero) of compact input column rho
+__host__ __device__ constexpr int channel_of_rho16(int rho) {
+    if (rho < 64) return slot16_channel(8 * (rho >> 5) + (rho & 7), (rho >> 3) & 3);
+    return slot16_channel(16 + (rho & 3), (rho - 64) >> 2);
+}
+__host__ __device__ constexpr int rho16_of_channel(int ch) {       // ch: 0..72, or kSlotOne
+    for (int rho = 0; rho < Lds16::KP; ++rho)
+        if (channel_of_rho16(rho) == ch) return rho;
+    return -1;
+}
+// position of hidden unit h in the contraction order of the chained products, and its inverse
+__host__ __device__ constexpr int pos16(int h) { return 32 * (h >> 5) + 8 * ((h >> 2) & 3) + 4 * ((h >> 4) & 1) + (h & 3); }
+__host__ __device__ constexpr int hid16(int pos) { return 16 * (2 * (pos >> 5) + ((pos >> 2) & 1)) + 4 * ((pos >> 3) & 3) + (pos & 3); }
+
+typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+__device__ __forceinline__ bf16x8 ld_frag(lds_cbf* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<lds_cu4*>(p)); }       // ds_read_b128
+__device__ __forceinline__ void st_frag(lds_bf* p, const bf16x8& f) { *reinterpret_cast<lds_u4*>(p) = __builtin_bit_cast(u32x4, f); }   // ds_write_b128
+__device__ __forceinline__ bf16x8 half_frag(s16x4 a) {               // k = 0..3 real, 4..7 zero
+    const s16x8 v = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 mfma16_split(const Frag2& a, const Frag2& b, f32x4 c) {
+    c = mfma16_bf(a.lo, b.hi, c);
+    c = mfma16_bf(a.hi, b.lo, c);
+    return mfma16_bf(a.hi, b.hi, c);
+}
+__device__ __forceinline__ Frag2 split_pair(const f32x4& a, const f32x4& b) {       // registers of row tiles 2s, 2s + 1 = k-step s
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return split8(x);
+}
+__device__ __forceinline__ lds_bf* opaque(lds_bf* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// raw grid values of the lane's cell: G0 corner g (12 channels), G1 channels 3g..3g+2 at the 4 corners
+struct CellRaw16 {
+    float g0[kC];
+    float g1[4 * 3];     // [corner q][cc]
+};
+struct GridAcc16 {
+    float g1[4 * 3];     // [corner q][cc]; the G0 sums live in the dX accumulator tiles
+};
+
+template <class GT>
+__device__ __forceinline__ void gather_cell16(const FusedParams& p, uint32_t off0, uint32_t off1, int g, CellRaw16& raw, bool hg0, bool hg1) {
+    if (hg0) {
+        const uint32_t voff = off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
+#pragma unroll
+        for (int c = 0; c < kC; ++c) raw.g0[c] = grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);
+    }
+    if (hg1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t voff = off1 + (uint32_t)p.g1.at(q >> 1, q & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) raw.g1[q * 3 + cc] = grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff);
+        }
+    }
+}
+
+// the lane's 20 real slots for the sample at absolute coordinates q (slots 15 and 20..23 are zero and never materialised)
+template <class L, bool HG0, bool HG1>
+__device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3], int g, float (&xs)[20], EncCtx& cx, const CellRaw16& raw) {
+    const nic_path_desc& d = p.d;
+    const int e = d.log2_step;
+    const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
+    const int x0 = clampi(ax.i0, 0, p.g0.nx - 2), y0 = clampi(ay.i0, 0, p.g0.ny - 2);
+    const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2);
+    cx.off0 = (uint32_t)p.g0.at(x0, y0, 0);
+    cx.off1 = (uint32_t)p.g1.at(x1, y1, 0);
+    cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = 0.f;
+    // --- G1 corner values of channels 3g + cc (issued first: the blend is the first consumer of a gather)
+    float g1v[12];
+    {
+        uint32_t voff[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) voff[c4] = cx.off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+                g1v[c4 * 3 + cc] = HG1 ? raw.g1[c4 * 3 + cc] : grid_elem<float>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[c4]);
+    }
+    // --- G0 corner g: (dx, dy) = (g >> 1, g & 1) (fp_def.py:82-85)
+    {
+        const uint32_t voff = cx.off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
+#pragma unroll
+        for (int c = 0; c < kC; ++c) xs[c] = HG0 ? raw.g0[c] : grid_elem<float>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- PE rows 3g .. 3g+2: dimension g >> 1, rows 3 (g & 1) + i of its block (utils.py:198-227); LOD / the constant one
+    {
+        const float c = (g >> 1) ? ay.t1 : ax.t1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = 3 * (g & 1) + i;
+            float v;
+            if (L::PE == NIC_PE_TRIANGULAR) {
+                v = tri_pe_row(c, r, kP);
+            } else {
+                const int k = r >> 1;
+                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
+                float sv, cv;
+                sincos_cw(mul_rn(c, dv), sv, cv);
+                v = (r & 1) ? cv : sv;
+            }
+            xs[15 + i] = v;
+        }
+        xs[18] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- G1 blend with the reference's factor order (fp_def.py:141-144)
+    const G1Factors gf = g1_factors<2>(d.g1_weight_mode, cx.kx, cx.ky, 0.f);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const uint32_t b = (gf.bits >> (3 * c4)) & 7u;
+            float v = g1v[c4 * 3 + cc];
+            v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+            v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+            sum = c4 == 0 ? v : add_rn(sum, v);
+        }
+        xs[12 + cc] = sum;
+    }
+}
+// xs index of slot sigma (slot 15 is dropped from the register array: xs[12..14] = slots 12..14, xs[15..18] = slots 16..19)
+__host__ __device__ constexpr int xs_of_slot(int s) { return s < 15 ? s : s - 1; }
+
+// The in-kernel noise of fused_kernel, value for value (oracle/nic_oracle.py::kernel_noise): stream h = g >> 1 of the sample, value v
+// of the stream in generator block 3h + (v >> 4), byte v & 15.  Quarter (h, e = g & 1) needs v = 12e + c (G0), 24 + 3e + cc (G1),
+// 30 + 3e + i (PE) and 36 (LOD, g = 0): it runs block 3h + e and block 3h + 2 and swaps two words of the first with its partner
+// quarter (lane ^ 16).
+template <class L>
+__device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int g, float (&xs)[20]) {
+    if (ns.mode == NIC_NOISE_NONE) return;
+    if (ns.mode == NIC_NOISE_TENSOR) {
+        const float* row = ns.tensor + n_local * L::CIN;
+#pragma unroll
+        for (int s = 0; s < 20; ++s) {
+            if (s == 15) continue;
+            const int ch0 = slot16_channel(s, 0);
+            if (s == 19) { xs[18] += g == 0 ? row[72] : 0.f; continue; }
+            // channel is affine in g for every other real slot
+            const int stride = slot16_channel(s, 1) - ch0;
+            xs[xs_of_slot(s)] += row[ch0 + stride * g];
+        }
+        return;
+    }
+    const int h = g >> 1, e = g & 1;
+    const U4 A = noise_block(ns, sample_global, 3 * h + e);
+    const U4 C = noise_block(ns, sample_global, 3 * h + 2);
+    const uint32_t pz = (uint32_t)__shfl_xor((int)A.z, 16), pw = (uint32_t)__shfl_xor((int)A.w, 16);
+    // words holding v = 12e + c, c = 0..11: block 0 words 0..2 (e = 0) / block 0 word 3, block 1 words 0, 1 (e = 1)
+    const uint32_t w0 = e ? pw : A.x, w1 = e ? A.x : A.y, w2 = e ? A.y : A.z;
+    const uint32_t b1w2 = e ? A.z : pz, b1w3 = e ? A.w : pw;          // block 1 words 2, 3
+#pragma unroll
+    for (int c = 0; c < 12; ++c) xs[c] += noise_from_byte(ns, c < 4 ? w0 : (c < 8 ? w1 : w2), c & 3);
+    // v = 24 + 3e + cc: bytes 3e .. 3e+2 of the 64-bit value (b1w3 : b1w2)
+    const uint32_t g1w = __builtin_amdgcn_alignbyte(b1w3, b1w2, 3u * (uint32_t)e);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) xs[12 + cc] += noise_from_byte(ns, g1w, cc);
+    // v = 30 + 3e + i: e = 0: bytes 2, 3 of b1w3 and byte 0 of block 2 word 0; e = 1: bytes 1..3 of block 2 word 0
+    const uint32_t pew = __builtin_amdgcn_alignbyte(C.x, e ? C.x : b1w3, e ? 1u : 2u);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xs[15 + i] += noise_from_byte(ns, pew, i);
+    const float nl = noise_from_byte(ns, C.y, 0);                       // v = 36: the LOD channel (quarter 0)
+    xs[18] += g == 0 ? nl : 0.f;
+}
+
+// G1 sums of the lanes whose G0 cells share a G1 cell are added across lanes before the flush (see combine_g1_lanes)
+__device__ __forceinline__ void combine_g1_lanes16(GridAcc16& ga, uint32_t off1, const int (&blk)[3], int lane, int lw) {
+    const int T[2] = {1 << lw, 16 >> lw};
+    const int STR[2] = {1, 1 << lw};
+    const int pl = lane & 15;
+    const int lc[2] = {pl & (T[0] - 1), pl >> lw};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const bool odd = blk[a] & 1;
+        const int pc = lc[a] + (odd ? -1 : 1);
+        const bool inb = pc >= 0 && pc < T[a];
+        const int partner = inb ? lane + (odd ? -STR[a] : STR[a]) : lane;
+        const bool pair = inb && (uint32_t)__shfl((int)off1, partner) == off1;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float pv = __shfl(ga.g1[i], partner);
+            ga.g1[i] = pair ? (odd ? 0.f : ga.g1[i] + pv) : ga.g1[i];
+        }
+    }
+}
+
+// =====================================================================================================
+template <class L, int MODE>
+__global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
+    using S = Lds16;
+    static_assert(L::DIM == 2 && L::CIN == 73, "the 16-sample training kernel is built for the 2D slot layouts");
+    static_assert(MODE != MODE_INFER, "training kernel");
+    constexpr int LD1 = S::LD1, LD2 = S::LD2, LD3 = S::LD3, LDZ = S::LDZ, LDX = S::LDX;
+    constexpr bool HG0 = (NIC_T16_HOIST & 1) != 0, HG1 = (NIC_T16_HOIST & 2) != 0;
+    __shared__ __attribute__((aligned(16))) __bf16 smem16[S::TOTAL];
+    lds_bf* const sm = (lds_bf*)smem16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g = lane >> 4;
+
+    // ---------------- prologue: decoder weights -> bf16 hi / lo images (W1 in compact rho order with b1 in the column of the
+    // constant-one slot; W2 / W3 columns in position order), per-wave images zeroed
+    for (int idx = tid; idx < kH * LD1; idx += 512) {
+        const int o = idx / LD1, rho = idx - o * LD1;
+        const int ch = channel_of_rho16(rho);
+        const float v = ch >= 0 ? p.W[0][o * L::CIN + ch] : (ch == kSlotOne ? p.b[0][o] : 0.f);
+        const __bf16 hi = (__bf16)v;
+        sm[S::OFF_W1 + idx] = hi;
+        sm[S::OFF_W1 + S::W1LO + idx] = (__bf16)(v - (float)hi);
+    }
+    for (int idx = tid; idx < kH * LD2; idx += 512) {
+        const int o = idx / LD2, ps = idx - o * LD2;
+        const float v = ps < kH ? p.W[1][o * kH + hid16(ps)] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        sm[S::OFF_W2 + idx] = hi;
+        sm[S::OFF_W2 + S::W2LO + idx] = (__bf16)(v - (float)hi);
+    }
+    for (int idx = tid; idx < 4 * LD3; idx += 512) {
+        const int c = idx / LD3, ps = idx - c * LD3;
+        const float v = (c < 3 && ps < kH) ? p.W[2][c * kH + hid16(ps)] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        sm[S::OFF_W3 + idx] = hi;
+        sm[S::OFF_W3 + S::W3LO + idx] = (__bf16)(v - (float)hi);
+    }
+    lds_f* const Bs = (lds_f*)(sm + S::OFF_B);                   // b2 [64] in natural order, b3 [4]
+    if (tid < kH) Bs[tid] = p.b[1][tid];
+    if (tid >= kH && tid < kH + 4) Bs[tid] = tid - kH < 3 ? p.b[2][tid - kH] : 0.f;
+    for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
+    __syncthreads();
+
+    // ---------------- launch-lifetime accumulators: the weight-gradient tiles this wave owns
+    f32x16 accW2 = f32x16(0.f);          // dW2 tile (wave & 3), samples of waves 4 (wave >> 2) ..
+    f32x16 accW1 = f32x16(0.f);          // dW1 tile (wave & 3) of the first 64 input columns, same samples
+    f32x4 accT = f32x4(0.f);             // dW1 columns 64..79, rows 16 (wave & 3).., k-steps 2 (wave >> 2), + 1
+    f32x4 accW3q = f32x4(0.f), accB2q = f32x4(0.f);
+    float accB3[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
+    const int T4 = wave & 3, kh = wave >> 2;
+    const int to = T4 >> 1, tk = T4 & 1;
+
+    // ---------------- per-lane LDS bases
+    lds_bf* const img0 = sm + S::OFF_IMG;
+    lds_bf* const imgw = img0 + wave * S::SPW;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, h32 = lane >> 5, cg = (lane >> 4) & 1;
+
+    // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave); see fused_kernel.hpp
+    const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
+    const int64_t n_units = p.n_tiles << p.rg_log2;
+    const int64_t chunk = (((n_units + 7) >> 3) + 7) & ~(int64_t)7;
+    const int64_t t_begin = xcd * chunk;
+    const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
+    const int lstride = nb8 * 8;
+    const int64_t base0 = t_begin + (int64_t)(blockIdx.x >> 3) * 8;
+    const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
+    const int rounds_unit = (p.niter * p.passes) >> p.rg_log2;
+    const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);
+    const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || p.rg_log2 == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+
+    for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
+        const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
+        const bool tile_ok = base + wave < t_end;
+        const int64_t unit = tile_ok ? base + wave : t_end - 1;
+        const int64_t tile = unit >> p.rg_log2;
+        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * rounds_unit;
+        if (shift) {
+            if (kk == 0) { it_begin += shift; it_len -= shift; }
+            else if (kk == n_my) it_len = shift;
+        }
+        // ---------- macro-tile -> this lane's cell (absolute block coordinates) and crop
+        int lw = 4;
+        int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
+        const int crop = (int)(tile / p.tiles_per_crop);
+        {
+            const int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
+            int boff[2];
+            if (p.edge_lw < 0 || tt < p.tiles_main) {
+                boff[1] = tt % p.tiles_y;                 // regular tile: 16 x 1 cells
+                boff[0] = (tt / p.tiles_y) * 16;
+            } else {
+                lw = p.edge_lw;                           // edge tile: 2^lw x (16 >> lw) cells
+                boff[1] = (tt - (int)p.tiles_main) * (16 >> lw);
+                boff[0] = p.full_x * 16;
+            }
+            const int lc[2] = {n16 & ((1 << lw) - 1), n16 >> lw};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                org[a] = p.origins[crop * 2 + a];
+                blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
+            }
+        }
+        GridAcc16 gacc;
+        f32x4 dxacc[4];                                                      // tiles 0..2: the cell's G0 gradient sums (persistent over the rounds)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) gacc.g1[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dxacc[t] = f32x4(0.f);
+        uint32_t blk_off0, blk_off1;
+        CellRaw16 raw;
+        {
+            const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, 0};
+            cell_offsets<L>(p, qb, blk_off0, blk_off1);
+            gather_cell16<float>(p, blk_off0, blk_off1, g, raw, HG0, HG1);
+        }
+
+        for (int it = it_begin; it < it_begin + it_len; ++it) {
+            // ---------- per-lane LDS bases, opaque inside the loop (see fused_kernel.hpp)
+            lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
+            lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 64 + 4 * g));
+            lds_cbf* const w2_row = opaque((lds_cbf*)(sm + S::OFF_W2 + n16 * LD2 + 8 * g));
+            lds_cbf* const w3_row = opaque((lds_cbf*)(sm + S::OFF_W3 + (n16 < 3 ? n16 : 3) * LD3 + 8 * g));
+            lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
+            lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + (4 * g + q4) * LD2 + 8 * p4));
+            lds_cbf* const w3_tr = opaque((lds_cbf*)(sm + S::OFF_W3 + q4 * LD3 + 8 * p4));
+            lds_cf* const b2_row = opaque(Bs + 4 * g);
+            lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);                 // fragment stores: row n, columns 32 s + 8 g
+            lds_bf* const a1_st = opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
+            lds_bf* const x_st = opaque(imgw + S::OFF_X + n16 * LDX + 8 * g);
+            lds_bf* const x_st2 = opaque(imgw + S::OFF_X + n16 * LDX + 64 + 4 * g);
+            lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
+            // 4x4x4 operands (own samples): B = column `lane` of samples 4 q' + r; A = dZ3[c = lane & 3][those samples]
+            lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + 4 * q4 * LDZ + 16 * g + 4 * p4));
+            lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (lane & 3) * 16));
+            // 32x32x16 weight-gradient operands: samples 4 q' + 2 (lane >> 5) + rd of a source wave, columns 32 tile + 16 cg + 4 p4
+            lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+            lds_cbf* const a1_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_A1 + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
+            lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_X + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
+            // 16x16x32 tail operands: quarter G reads source wave 4 kh + 2 uu + (G >> 1), samples 4 q' + 2 (G & 1) + rd
+            lds_cbf* const dz_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + (4 * q4 + 2 * (g & 1)) * LDZ + 16 * T4 + 4 * p4));
+            lds_cbf* const x_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + S::OFF_X + (4 * q4 + 2 * (g & 1)) * LDX + 64 + 4 * p4));
+
+            // ---------- which sample does this lane own in this round
+            bool valid = tile_ok;
+            int64_t n;
+            int q[3] = {0, 0, 0};
+            {
+                const int m1 = (1 << p.lm) - 1;
+                const int pass = it >> (p.lm * 2), its = it & (p.niter - 1);
+                const int j[2] = {its >> p.lm, its & m1};
+                const int ext[2] = {p.d.extent[0], p.d.extent[1]};
+                int idx[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int i = (blk[a] << p.lm) + j[a] - org[a];
+                    valid = valid && i >= 0 && i < ext[a];
+                    idx[a] = i < 0 ? 0 : (i >= ext[a] ? ext[a] - 1 : i);
+                    q[a] = org[a] + idx[a];
+                }
+                n = ((int64_t)crop * p.passes + pass) * p.n_per_crop + (int64_t)idx[0] * ext[1] + idx[1];
+            }
+            // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
+            float tgt[3] = {0.f, 0.f, 0.f};
+            if (MODE == MODE_TRAIN_IMG) {
+                const int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (p.timg_u8) {
+                        const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                        const float t0 = mul_rn(u, p.timg_rcp);
+                        tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
+                    } else {
+                        tgt[c] = (reinterpret_cast<const float*>(p.timg) + c * p.timg_cs)[off];
+                    }
+                }
+            } else {
+                const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
+            }
+            // ---------- input slots
+            float xs[20];
+            EncCtx cx;
+            encode16<L, HG0, HG1>(p, q, g, xs, cx, raw);
+            add_noise16<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+
+            // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
+            f32x4 a1[4], d1[4];
+            {
+                f32x4 z[4] = {f32x4(0.f), f32x4(0.f), f32x4(0.f), f32x4(0.f)};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag2 af[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        af[t].hi = ld_frag(&w1_row[16 * t * LD1 + 32 * s]);
+                        af[t].lo = ld_frag(&w1_row[S::W1LO + 16 * t * LD1 + 32 * s]);
+                    }
+                    // slots 8s .. 8s+7 (slot 15 is the zero slot)
+                    const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6],
+                                         s == 0 ? xs[7] : 0.f};
+                    const Frag2 bf = split8(xv);
+                    st_frag(&x_st[32 * s], bf.hi);
+                    st_frag(&x_st[S::XLO + 32 * s], bf.lo);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
+                }
+                {   // k-step 2: slots 16..19, compact columns 64 + 4 g + j
+                    Frag2 af[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        af[t].hi = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]));
+                        af[t].lo = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[S::W1LO + 16 * t * LD1]));
+                    }
+                    const float xv[8] = {xs[15], xs[16], xs[17], xs[18], 0.f, 0.f, 0.f, 0.f};
+                    const Frag2 bf = split8(xv);
+                    const s16x8 bh = __builtin_bit_cast(s16x8, bf.hi), bl = __builtin_bit_cast(s16x8, bf.lo);
+                    *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
+                    *reinterpret_cast<lds_s16x4*>(x_st2 + S::XLO) = s16x4{bl[0], bl[1], bl[2], bl[3]};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------- layer 2
+            f32x4 a2[4], d2[4];
+            {
+                f32x4 z[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) z[t] = ld4(&b2_row[16 * t]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag2 af[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        af[t].hi = ld_frag(&w2_row[16 * t * LD2 + 32 * s]);
+                        af[t].lo = ld_frag(&w2_row[S::W2LO + 16 * t * LD2 + 32 * s]);
+                    }
+                    const Frag2 bf = split_pair(a1[2 * s], a1[2 * s + 1]);
+                    st_frag(&a1_st[32 * s], bf.hi);
+                    st_frag(&a1_st[S::DZLO + 32 * s], bf.lo);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
+            // the a2 image of dW3 (the DZ region is free until dZ2 is stored)
+            float yv[3];
+            {
+                f32x4 z3 = f32x4(0.f);
+                Frag2 af[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    af[s].hi = ld_frag(&w3_row[32 * s]);
+                    af[s].lo = ld_frag(&w3_row[S::W3LO + 32 * s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const Frag2 bf = split_pair(a2[2 * s], a2[2 * s + 1]);
+                    st_frag(&dz_st[32 * s], bf.hi);
+                    st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
+                    z3 = mfma16_split(af[s], bf, z3);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[kH + c]);
+            }
+            const bool own = valid && g == 0;
+            if (p.y != nullptr && own) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------- dZ3
+            float dz3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gr;
+                if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
+                    const float diff = own ? yv[c] - tgt[c] : 0.f;
+                    accLoss += diff * diff;
+                    gr = p.grad_scale * diff;
+                } else {
+                    gr = own ? tgt[c] : 0.f;
+                }
+                dz3[c] = gr * yv[c] * (1.0f - yv[c]);
+                accB3[c] += dz3[c];
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const __bf16 hi = (__bf16)dz3[c];
+                    d3_st[c * 16] = hi;
+                    d3_st[64 + c * 16] = (__bf16)(dz3[c] - (float)hi);
+                }
+            }
+            wave_lds_fence();
+            // ---------- dW3[c][pos = lane] += sum_n dZ3[c][n] a2[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
+            {
+                s16x4 bh[4], bl[4], ah[4], al[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bh[r] = tr4(&dz_b44[r * LDZ]);
+                    bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
+                    ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
+                    al[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[64 + 4 * r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accW3q = mfma4_bf(al[r], bh[r], accW3q);
+                    accW3q = mfma4_bf(ah[r], bl[r], accW3q);
+                    accW3q = mfma4_bf(ah[r], bh[r], accW3q);
+                }
+            }
+            // ---------- dA2 = W3^T dZ3 (k = c: quarter 0 carries dZ3 in elements 0..2, everything else is zero), dZ2 = dA2 * gelu'(Z2)
+            f32x4 dz2[4];
+            {
+                const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+                const Frag2 bf = split8(dzv);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const s16x4 ahh = tr4(&w3_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
+                    const s16x4 all = tr4(&w3_tr[S::W3LO + 32 * (t >> 1) + 4 * (t & 1)]);
+                    Frag2 af;
+                    af.hi = join8(ahh, ahh);
+                    af.lo = join8(all, all);
+                    dz2[t] = mfma16_split(af, bf, f32x4(0.f)) * d2[t];
+                }
+            }
+            wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
+            // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are the dZ2 image of the weight-gradient product
+            f32x4 dz1[4];
+            {
+                f32x4 acc[4] = {f32x4(0.f), f32x4(0.f), f32x4(0.f), f32x4(0.f)};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag2 af[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int co = 32 * (t >> 1) + 4 * (t & 1);
+                        af[t].hi = join8(tr4(&w2_tr[32 * s * LD2 + co]), tr4(&w2_tr[(32 * s + 16) * LD2 + co]));
+                        af[t].lo = join8(tr4(&w2_tr[S::W2LO + 32 * s * LD2 + co]), tr4(&w2_tr[S::W2LO + (32 * s + 16) * LD2 + co]));
+                    }
+                    const Frag2 bf = split_pair(dz2[2 * s], dz2[2 * s + 1]);
+                    st_frag(&dz_st[32 * s], bf.hi);
+                    st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma16_split(af[t], bf, acc[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dz1[t] = acc[t] * d1[t];
+            }
+            wave_lds_fence();
+            // ---------- db2[pos = lane] += sum_n dZ2[pos][n]: 4x4x4 MFMAs against a block of ones
+            {
+                const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+                s16x4 bh[4], bl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
+                    bh[r] = tr4(&dz_b44[r * LDZ]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accB2q = mfma4_bf(ones, bl[r], accB2q);
+                    accB2q = mfma4_bf(ones, bh[r], accB2q);
+                }
+            }
+            wg_lds_barrier();
+            // ---------- dW2 tile (to, tk) += sum over the samples of waves 4 kh .. 4 kh + 3 of dZ2[o][n] a1[k][n]
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Frag2 af, bf;
+                af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                bf.lo = join8(tr4(&a1_t32[v * S::SPW + S::DZLO]), tr4(&a1_t32[v * S::SPW + S::DZLO + LDZ]));
+                af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
+                bf.hi = join8(tr4(&a1_t32[v * S::SPW]), tr4(&a1_t32[v * S::SPW + LDZ]));
+                accW2 = mfma_split(af, bf, accW2);
+            }
+            wg_lds_barrier();                                              // everyone is done reading dZ2 before dZ1 replaces it
+            // ---------- dX = W1^T dZ1 for the grid slots (tiles 0..3 = slots 0..15); the split dZ1 fragments are the dZ1 image.
+            // Tiles 0..2 (the G0 channels) keep their running sums over the rounds in the product's C operand.
+            {
+                dxacc[3] = f32x4(0.f);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag2 af[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int co = 32 * (t >> 1) + 4 * (t & 1);
+                        af[t].hi = join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
+                        af[t].lo = join8(tr4(&w1_tr[S::W1LO + 32 * s * LD1 + co]), tr4(&w1_tr[S::W1LO + (32 * s + 16) * LD1 + co]));
+                    }
+                    const Frag2 bf = split_pair(dz1[2 * s], dz1[2 * s + 1]);
+                    st_frag(&dz_st[32 * s], bf.hi);
+                    st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dxacc[t] = mfma16_split(af[t], bf, dxacc[t]);
+                }
+                const G1Factors gf = g1_factors<2>(p.d.g1_weight_mode, cx.kx, cx.ky, 0.f);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float w = g1_corner_factor<2>(gf, c4);
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) gacc.g1[c4 * 3 + cc] = fmaf(dxacc[3][cc], w, gacc.g1[c4 * 3 + cc]);
+                }
+            }
+            wg_lds_barrier();
+            // ---------- dW1: columns 0..63 as the 32x32 tile (to, tk) over the same four source waves ...
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Frag2 af, bf;
+                af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                bf.lo = join8(tr4(&x_t32[v * S::SPW + S::XLO]), tr4(&x_t32[v * S::SPW + S::XLO + LDX]));
+                af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
+                bf.hi = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
+                accW1 = mfma_split(af, bf, accW1);
+            }
+            // ... columns 64..79 as a 16x16 tile (rows 16 T4 ..): two k-steps of 32 samples (two source waves each)
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                Frag2 af, bf;
+                af.hi = join8(tr4(&dz_t16[2 * uu * S::SPW]), tr4(&dz_t16[2 * uu * S::SPW + LDZ]));
+                af.lo = join8(tr4(&dz_t16[2 * uu * S::SPW + S::DZLO]), tr4(&dz_t16[2 * uu * S::SPW + S::DZLO + LDZ]));
+                bf.hi = join8(tr4(&x_t16[2 * uu * S::SPW]), tr4(&x_t16[2 * uu * S::SPW + LDX]));
+                bf.lo = join8(tr4(&x_t16[2 * uu * S::SPW + S::XLO]), tr4(&x_t16[2 * uu * S::SPW + S::XLO + LDX]));
+                accT = mfma16_split(af, bf, accT);
+            }
+            wg_lds_barrier();                      // all reads of dZ1 / X done before the next round overwrites them
+        }  // rounds of one macro-tile
+
+        // ---------- flush of the cell's gradient sums
+        {
+            combine_g1_lanes16(gacc, blk_off1, blk, lane, lw);
+            bool flush = true;
+            if (NIC_GROUP_SUM && p.rg_log2 > 0) {                          // launch-uniform: groups of one macro-tile sit in one workgroup
+                lds_f* const reg0 = (lds_f*)img0;
+                constexpr int REGION = S::SPW / 2;                         // floats per wave
+                static_assert(24 * 64 <= REGION, "group-sum scratch");
+                int leader = wave;
+                if (tile_ok)
+                    for (int w = wave - 1; w >= 0; --w)
+                        if (((base + w) >> p.rg_log2) == tile) leader = w;
+                if (leader != wave) {
+                    lds_f* const mine = opaque(reg0 + wave * REGION + lane);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) mine[(12 + i) * 64] = gacc.g1[i];
+                }
+                wg_lds_barrier();
+                if (leader == wave && tile_ok) {
+                    for (int w = wave + 1; w < 8; ++w) {
+                        if (base + w >= t_end || ((base + w) >> p.rg_log2) != tile) break;
+                        lds_cf* const theirs = opaque(reg0 + w * REGION + lane);
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] += theirs[i * 64];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) gacc.g1[i] += theirs[(12 + i) * 64];
+                    }
+                }
+                wg_lds_barrier();
+                flush = leader == wave;
+                // the scratch overlays the images: zero what was written (rows of D3 / padding are assumed zero by nobody, but the
+                // images are rewritten before they are read in every round - nothing to restore)
+            }
+            if (flush) {
+                const uint32_t voff0 = blk_off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    const float v = dxacc[c >> 2][c & 3];
+                    float* plane = p.g0_grad + (int64_t)c * p.g0.plane;
+                    if (v != 0.f) atomicAdd(plane + voff0, v);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const uint32_t voff = blk_off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const float v = gacc.g1[c4 * 3 + cc];
+                        float* plane = p.g1_grad + (int64_t)cc * p.g1.plane;
+                        if (v != 0.f) atomicAdd(plane + voff, v);
+                    }
+                }
+            }
+        }
+    }  // macro-tile loop
+
+    // ---------------- one record per workgroup
+    float* rec = p.partials + (int64_t)blockIdx.x * S::REC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        rec[S::REC_W2 + wave * 1024 + r * 64 + lane] = accW2[r];
+        rec[S::REC_W1 + wave * 1024 + r * 64 + lane] = accW1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rec[S::REC_TAIL + wave * 256 + r * 64 + lane] = accT[r];
+    float* tail = rec + S::REC_WAVE + wave * 320;
+    tail[lane] = accB2q[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tail[64 + 64 * c + lane] = accW3q[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = c < 3 ? accB3[c] : accLoss;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) tail[256 + c] = v;
+    }
+}
+
+// =====================================================================================================
+// Fixed-order reduction of the per-workgroup records of fused_train16_kernel into the decoder gradients (nn.Linear layouts) and
+// the loss.  Output index space: W1 [64][73] | b1 [64] | W2 [64][64] | b2 [64] | W3 [3][64] | b3 [3] | loss.
+template <class L>
+__global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+    using S = Lds16;
+    constexpr int N_W1 = kH * L::CIN, N_B1 = kH, N_W2 = kH * kH, N_B2 = kH, N_W3 = 3 * kH, N_B3 = 3;
+    constexpr int N_OUT = N_W1 + N_B1 + N_W2 + N_B2 + N_W3 + N_B3 + 1;
+    __shared__ float red[8][32];
+    const int slice = threadIdx.x >> 5;
+    const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool live = gid < N_OUT;
+    int nsrc = 0, off0 = 0, stride = 0;
+    float* dst = nullptr;
+    // element (row i, col j) of a 32x32 accumulator tile: register (i & 3) + 4 (i >> 3) of lane j + 32 ((i >> 2) & 1)
+    auto tile32 = [](int i, int j) { return ((i & 3) + 4 * (i >> 3)) * 64 + j + 32 * ((i >> 2) & 1); };
+    if (live) {
+        int t = gid;
+        if (t < N_W1 + N_B1) {
+            int o, ch;
+            if (t < N_W1) { o = t / L::CIN; ch = t - o * L::CIN; dst = gr.w[0] ? gr.w[0] + t : nullptr; }
+            else { o = t - N_W1; ch = kSlotOne; dst = gr.b[0] ? gr.b[0] + o : nullptr; }
+            const int rho = rho16_of_channel(ch), po = pos16(o);
+            if (rho < 64) {
+                const int tile = 2 * (po >> 5) + (rho >> 5);
+                off0 = S::REC_W1 + tile * 1024 + tile32(po & 31, rho & 31);
+                nsrc = 2; stride = 4 * 1024;
+            } else {
+                // 16x16 tile: row m = po & 15 -> register m & 3 of lane 16 (m >> 2) + col
+                const int m = po & 15;
+                off0 = S::REC_TAIL + (po >> 4) * 256 + (m & 3) * 64 + 16 * (m >> 2) + (rho - 64);
+                nsrc = 2; stride = 4 * 256;
+            }
+        } else if ((t -= N_W1 + N_B1) < N_W2) {
+            const int o = t / kH, k = t - o * kH;
+            const int po = pos16(o), pk = pos16(k);
+            const int tile = 2 * (po >> 5) + (pk >> 5);
+            off0 = S::REC_W2 + tile * 1024 + tile32(po & 31, pk & 31);
+            nsrc = 2; stride = 4 * 1024;
+            dst = gr.w[1] ? gr.w[1] + t : nullptr;
+        } else if ((t -= N_W2) < N_B2) {
+            off0 = S::REC_WAVE + pos16(t); nsrc = 8; stride = 320;
+            dst = gr.b[1] ? gr.b[1] + t : nullptr;
+        } else if ((t -= N_B2) < N_W3) {
+            const int c = t / kH, k = t - c * kH;
+            off0 = S::REC_WAVE + 64 + 64 * c + pos16(k); nsrc = 8; stride = 320;
+            dst = gr.w[2] ? gr.w[2] + t : nullptr;
+        } else if ((t -= N_W3) < N_B3) {
+            off0 = S::REC_WAVE + 256 + t; nsrc = 8; stride = 320;
+            dst = gr.b[2] ? gr.b[2] + t : nullptr;
+        } else {
+            off0 = S::REC_WAVE + 259; nsrc = 8; stride = 320;
+            dst = loss;
+        }
+    }
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
+    const int per = (n_rec + 7) >> 3;
+    const int w_lo = slice * per, w_hi = (w_lo + per < n_rec) ? w_lo + per : n_rec;
+    if (live) {
+        for (int k = 0; k < nsrc; ++k) {
+            const float* src = partials + off0 + k * stride;
+            int w = w_lo;
+            for (; w + 8 <= w_hi; w += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
+            }
+            for (; w < w_hi; ++w) part[0] += src[(int64_t)w * S::REC];
+        }
+    }
+    red[slice][threadIdx.x & 31] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (slice != 0 || !live || dst == nullptr) return;
+    float acc = red[0][threadIdx.x];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
+    *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
+}
+
+}  // namespace nic

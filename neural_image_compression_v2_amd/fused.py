@@ -81,6 +81,7 @@ class PathGeometry:
     flags: int = 0                       # NIC_FLAG_* the caller vouches for (the wrappers add ORIGINS_ALIGNED when they can see it)
     split_bf16: bool = False             # 2D training steps: matrix products as hi + lo bf16 pairs on the bf16 pipe (NIC_FLAG_SPLIT_BF16)
     passes: int = 1                      # training steps: every crop sampled `passes` times in one launch (nic_path_desc.passes)
+    split_tile32: bool = False           # with split_bf16, 2D training: the 4-wave x 32-sample kernel instead of the 8-wave x 16-sample default
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -139,6 +140,8 @@ class PathGeometry:
         d.passes = int(self.passes)
         if self.split_bf16 or os.environ.get("NIC_FORCE_SPLIT_BF16") == "1":   # env: test switch for the whole suite
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
+        if self.split_tile32:
+            d.flags |= _lib.NIC_FLAG_SPLIT_TILE32
         return d
 
 
