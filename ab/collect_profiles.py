@@ -1,6 +1,7 @@
 """gpurun_out/prof_TAG (ab/profile.sh) -> profiles/TAG_{bench.json,kernel_stats.csv,pmc.csv} + profiles/traffic.json"""
 import csv, glob, json, os, sys
 tag = sys.argv[1]
+kern = sys.argv[2] if len(sys.argv) > 2 else "fused_train16_kernel"     # the dominant kernel of the default bench
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -12,7 +13,7 @@ out = []
 vals = {}
 for i in range(1, 6):
     f = glob.glob(os.path.join(src, f"pmc{i}", "*", "*_counter_collection.csv"))[0]
-    rows = [r for r in csv.DictReader(open(f)) if "fused_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
     disp = sorted({int(r["Dispatch_Id"]) for r in rows})
     dur = {}
     for r in rows:
@@ -20,7 +21,7 @@ for i in range(1, 6):
     names = sorted({r["Counter_Name"] for r in rows})
     sets = open(os.path.join(src, f"pmc{i}.set")).read().strip()
     out.append(f"# pass {i}: rocprofv3 --pmc {sets} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   "
-               f"(fused_kernel avg {sum(dur.values()) / len(dur):.3f} ms over {len(disp)} launches)")
+               f"({kern} avg {sum(dur.values()) / len(dur):.3f} ms over {len(disp)} launches)")
     for n in names:
         per = {}
         for r in rows:
@@ -32,7 +33,7 @@ for i in range(1, 6):
 open(os.path.join(dst, f"{tag}_pmc.csv"), "w").write("\n".join(out) + "\n")
 traffic = {"fused_kernel_bytes_per_launch": int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
            "raw": {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "TCC_EA0_ATOMIC_sum": vals["TCC_EA0_ATOMIC_sum"]},
-           "note": f"per launch of fused_kernel<Layout<1>,SRC_ENCODE,MODE_TRAIN_MSE> on the 4K workload; separate --pmc passes (profiles/{tag}_pmc.csv); "
+           "note": f"per launch of {kern} (Layout<1>, MODE_TRAIN_MSE) on the 4K workload; separate --pmc passes (profiles/{tag}_pmc.csv); "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of coalesced fetch bytes; the kernel's 4-12 B/lane reads are "
                    "outside the calibrated pattern, so this is an upper bound), WRITE_SIZE as is (exact for float atomics)."}
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)

@@ -218,6 +218,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     p.partials = (float*)workspace;
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
     balance_units(p, 1, wpw);
+    if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;     // the kernels count work units in 32 bits
     const int grid = grid_for(p.n_tiles << p.rg_log2, 1, wpw);
     const int n_rec = grid;                                   // one record per workgroup
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
@@ -244,7 +245,7 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
         if (layout > 0) rec = info_of(layout).rec;
     }
     if (train16_record_floats() > rec) rec = train16_record_floats();
-    const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float);      // one record per workgroup, at most one workgroup per CU
+    const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float) + (1u << 20);   // one record per workgroup, at most one workgroup per CU (+ 1 MiB: diagnostic builds)
     const size_t psnr = 1024 * sizeof(double);
     return fused > psnr ? fused : psnr;
 }

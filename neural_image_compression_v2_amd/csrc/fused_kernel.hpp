@@ -571,6 +571,23 @@ __device__ __forceinline__ void add_noise(const NoiseSrc& ns, uint64_t sample_gl
         }
         return;
     }
+    if constexpr (L::DIM == 2) {
+        // 2D: one block per G0 corner (noise_field, nic_device.hpp); lane half h holds corners 2h, 2h + 1.  Slot -> (corner of the
+        // half, field) is the same map for both halves.
+        const U4 b0 = noise_block(ns, sample_global, 2 * h), b1 = noise_block(ns, sample_global, 2 * h + 1);
+#pragma unroll
+        for (int s = 0; s < L::NSLOT; ++s) {
+            int e, f;
+            if (s < 24) { e = s / 12; f = s % 12; }
+            else if (s < 30) { e = (s - 24) / 3; f = 12 + (s - 24) % 3; }
+            else if (s >= 32 && s < 38) { e = (s - 32) / 3; f = 15 + (s - 32) % 3; }
+            else if (s == 38) { e = 0; f = 18; }
+            else continue;
+            const float v = noise_field(ns, e ? b1 : b0, f);
+            xs[s] += (s == 38) ? (h == 0 ? v : 0.f) : v;                          // slot 38 of half 1 is the bias carrier
+        }
+        return;
+    }
     using M = NoiseMap<L>;
     constexpr typename M::Table tab = M::make();
     U4 blk[M::NB];

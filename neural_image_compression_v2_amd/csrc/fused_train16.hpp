@@ -24,9 +24,6 @@
 #pragma once
 #include "fused_kernel.hpp"
 
-#ifndef NIC_T16_HOIST
-#define NIC_T16_HOIST 3       // bit 0: a cell's raw G0 values gathered once per macro-tile, bit 1: G1
-#endif
 
 namespace nic {
 
@@ -97,7 +94,26 @@ __device__ __forceinline__ lds_bf* opaque(lds_bf* p) {
     return p;
 }
 
-// raw grid values of the lane's cell: G0 corner g (12 channels), G1 channels 3g..3g+2 at the 4 corners
+// acc[t] += A_t x B for the NT row tiles of one k-step; the A fragments run PF tiles ahead of the MFMAs that consume them
+#ifndef NIC_T16_PF
+#define NIC_T16_PF 2
+#endif
+// ZERO: the first k-step of a product starts from C = 0 (an inline constant of the MFMA: no accumulator initialisation moves)
+template <int NT, bool ZERO = false, class LoadA>
+__device__ __forceinline__ void kstep16(f32x4 (&acc)[NT], const Frag2& bf, LoadA&& load_a) {
+    constexpr int PF = NIC_T16_PF < NT ? NIC_T16_PF : NT;
+    Frag2 af[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) af[t] = load_a(t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = mfma16_split(af[t % PF], bf, ZERO ? f32x4(0.f) : acc[t]);
+        if (t + PF < NT) af[t % PF] = load_a(t + PF);
+    }
+}
+
+// raw grid values of the lane's cell: G0 corner g (12 channels), G1 channels 3g..3g+2 at the 4 corners - gathered once per macro-tile
+// (every sample a lane handles inside one macro-tile lies in the same G0 cell and the same G1 cell)
 struct CellRaw16 {
     float g0[kC];
     float g1[4 * 3];     // [corner q][cc]
@@ -106,53 +122,44 @@ struct GridAcc16 {
     float g1[4 * 3];     // [corner q][cc]; the G0 sums live in the dX accumulator tiles
 };
 
-template <class GT>
-__device__ __forceinline__ void gather_cell16(const FusedParams& p, uint32_t off0, uint32_t off1, int g, CellRaw16& raw, bool hg0, bool hg1) {
-    if (hg0) {
-        const uint32_t voff = off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
+// Lane ids are re-derived from an opaque copy of the lane number at the start of every phase: everything computed from them
+// (LDS addresses, PE constants, select masks) is loop-invariant, and left alone the optimiser hoists it all out of the round loop
+// and the macro-tile loop - about 70 registers more than the 256 that two waves per SIMD allow, spilled to scratch.
+__device__ __forceinline__ int opaque_i(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Addressing of the once-per-macro-tile gathers and atomics: one wave-uniform tensor base (scalar registers) + a 32-bit byte offset
+// per lane that walks the channel planes (the per-plane scalar bases of fused_kernel cost ~60 scalar registers, which this kernel
+// does not have: they were spilled to vector lanes and read back with v_readlane in every round).
+__device__ __forceinline__ void gather_cell16(const FusedParams& p, uint32_t off0, uint32_t off1, int g, CellRaw16& raw) {
+    const uint32_t pb0 = (uint32_t)p.g0.plane * 4u, pb1 = (uint32_t)p.g1.plane * 4u;
+    {
+        uint32_t ob = (off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0)) * 4u;
+        const char* base = reinterpret_cast<const char*>(p.g0.p);
 #pragma unroll
-        for (int c = 0; c < kC; ++c) raw.g0[c] = grid_elem<GT>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);
+        for (int c = 0; c < kC; ++c, ob += pb0) raw.g0[c] = *reinterpret_cast<const float*>(base + ob);
     }
-    if (hg1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t voff = off1 + (uint32_t)p.g1.at(q >> 1, q & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+    for (int c4 = 0; c4 < 4; ++c4) {
+        uint32_t ob = (off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0)) * 4u + (uint32_t)(3 * g) * pb1;
+        const char* base = reinterpret_cast<const char*>(p.g1.p);
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) raw.g1[q * 3 + cc] = grid_elem<GT>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff);
-        }
+        for (int cc = 0; cc < 3; ++cc, ob += pb1) raw.g1[c4 * 3 + cc] = *reinterpret_cast<const float*>(base + ob);
     }
 }
 
-// the lane's 20 real slots for the sample at absolute coordinates q (slots 15 and 20..23 are zero and never materialised)
-template <class L, bool HG0, bool HG1>
+// the lane's 19 real slots for the sample at absolute coordinates q: xs[0..11] G0 corner g, xs[12..14] G1 channels 3g.. (blended),
+// xs[15..17] PE rows 3g.., xs[18] LOD (g = 0) / the constant one (g = 1).  Slot 15 and slots 20..23 are zero and never materialised.
+template <class L>
 __device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3], int g, float (&xs)[20], EncCtx& cx, const CellRaw16& raw) {
     const nic_path_desc& d = p.d;
     const int e = d.log2_step;
     const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
-    const int x0 = clampi(ax.i0, 0, p.g0.nx - 2), y0 = clampi(ay.i0, 0, p.g0.ny - 2);
-    const int x1 = clampi(ax.i1, 0, p.g1.nx - 2), y1 = clampi(ay.i1, 0, p.g1.ny - 2);
-    cx.off0 = (uint32_t)p.g0.at(x0, y0, 0);
-    cx.off1 = (uint32_t)p.g1.at(x1, y1, 0);
     cx.kx = ax.k1; cx.ky = ay.k1; cx.kz = 0.f;
-    // --- G1 corner values of channels 3g + cc (issued first: the blend is the first consumer of a gather)
-    float g1v[12];
-    {
-        uint32_t voff[4];
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) voff[c4] = cx.off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-                g1v[c4 * 3 + cc] = HG1 ? raw.g1[c4 * 3 + cc] : grid_elem<float>(p, p.g1.p, (int64_t)cc * p.g1.plane, voff[c4]);
-    }
-    // --- G0 corner g: (dx, dy) = (g >> 1, g & 1) (fp_def.py:82-85)
-    {
-        const uint32_t voff = cx.off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
-#pragma unroll
-        for (int c = 0; c < kC; ++c) xs[c] = HG0 ? raw.g0[c] : grid_elem<float>(p, p.g0.p, (int64_t)c * p.g0.plane, voff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < kC; ++c) xs[c] = raw.g0[c];
     // --- PE rows 3g .. 3g+2: dimension g >> 1, rows 3 (g & 1) + i of its block (utils.py:198-227); LOD / the constant one
     {
         const float c = (g >> 1) ? ay.t1 : ax.t1;
@@ -173,7 +180,6 @@ __device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3]
         }
         xs[18] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
     }
-    __builtin_amdgcn_sched_barrier(0);
     // --- G1 blend with the reference's factor order (fp_def.py:141-144)
     const G1Factors gf = g1_factors<2>(d.g1_weight_mode, cx.kx, cx.ky, 0.f);
 #pragma unroll
@@ -182,7 +188,7 @@ __device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3]
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const uint32_t b = (gf.bits >> (3 * c4)) & 7u;
-            float v = g1v[c4 * 3 + cc];
+            float v = raw.g1[c4 * 3 + cc];
             v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
             v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
             sum = c4 == 0 ? v : add_rn(sum, v);
@@ -190,13 +196,11 @@ __device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3]
         xs[12 + cc] = sum;
     }
 }
-// xs index of slot sigma (slot 15 is dropped from the register array: xs[12..14] = slots 12..14, xs[15..18] = slots 16..19)
+// xs index of slot sigma
 __host__ __device__ constexpr int xs_of_slot(int s) { return s < 15 ? s : s - 1; }
 
-// The in-kernel noise of fused_kernel, value for value (oracle/nic_oracle.py::kernel_noise): stream h = g >> 1 of the sample, value v
-// of the stream in generator block 3h + (v >> 4), byte v & 15.  Quarter (h, e = g & 1) needs v = 12e + c (G0), 24 + 3e + cc (G1),
-// 30 + 3e + i (PE) and 36 (LOD, g = 0): it runs block 3h + e and block 3h + 2 and swaps two words of the first with its partner
-// quarter (lane ^ 16).
+// The in-kernel noise of the 2D kernels (nic_device.hpp::noise_field, oracle/nic_oracle.py::kernel_noise): quarter g consumes
+// exactly generator block g of its sample - fields 0..11 the G0 channels, 12..14 the G1 channels, 15..17 the PE rows, 18 the LOD.
 template <class L>
 __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int g, float (&xs)[20]) {
     if (ns.mode == NIC_NOISE_NONE) return;
@@ -207,30 +211,15 @@ __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_
             if (s == 15) continue;
             const int ch0 = slot16_channel(s, 0);
             if (s == 19) { xs[18] += g == 0 ? row[72] : 0.f; continue; }
-            // channel is affine in g for every other real slot
-            const int stride = slot16_channel(s, 1) - ch0;
+            const int stride = slot16_channel(s, 1) - ch0;        // the channel is affine in g for every other real slot
             xs[xs_of_slot(s)] += row[ch0 + stride * g];
         }
         return;
     }
-    const int h = g >> 1, e = g & 1;
-    const U4 A = noise_block(ns, sample_global, 3 * h + e);
-    const U4 C = noise_block(ns, sample_global, 3 * h + 2);
-    const uint32_t pz = (uint32_t)__shfl_xor((int)A.z, 16), pw = (uint32_t)__shfl_xor((int)A.w, 16);
-    // words holding v = 12e + c, c = 0..11: block 0 words 0..2 (e = 0) / block 0 word 3, block 1 words 0, 1 (e = 1)
-    const uint32_t w0 = e ? pw : A.x, w1 = e ? A.x : A.y, w2 = e ? A.y : A.z;
-    const uint32_t b1w2 = e ? A.z : pz, b1w3 = e ? A.w : pw;          // block 1 words 2, 3
+    const U4 b = noise_block(ns, sample_global, g);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) xs[c] += noise_from_byte(ns, c < 4 ? w0 : (c < 8 ? w1 : w2), c & 3);
-    // v = 24 + 3e + cc: bytes 3e .. 3e+2 of the 64-bit value (b1w3 : b1w2)
-    const uint32_t g1w = __builtin_amdgcn_alignbyte(b1w3, b1w2, 3u * (uint32_t)e);
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc) xs[12 + cc] += noise_from_byte(ns, g1w, cc);
-    // v = 30 + 3e + i: e = 0: bytes 2, 3 of b1w3 and byte 0 of block 2 word 0; e = 1: bytes 1..3 of block 2 word 0
-    const uint32_t pew = __builtin_amdgcn_alignbyte(C.x, e ? C.x : b1w3, e ? 1u : 2u);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xs[15 + i] += noise_from_byte(ns, pew, i);
-    const float nl = noise_from_byte(ns, C.y, 0);                       // v = 36: the LOD channel (quarter 0)
+    for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
+    const float nl = noise_field(ns, b, 18);
     xs[18] += g == 0 ? nl : 0.f;
 }
 
@@ -255,19 +244,55 @@ __device__ __forceinline__ void combine_g1_lanes16(GridAcc16& ga, uint32_t off1,
     }
 }
 
+// Barrier among the four waves of one HALF of the workgroup (waves 4 kh .. 4 kh + 3).  The two halves never read each other's images
+// (a wave contracts its weight-gradient tiles over the samples of its own half), so the only thing a workgroup-wide s_barrier adds is
+// lockstep: all eight waves in the same phase at the same time, both waves of a SIMD wanting the same pipe.  With one monotonic LDS
+// counter per half the halves drift apart (and are started half a round apart), so a SIMD sees the vector-heavy encode / GELU phases
+// of one wave beside the matrix-heavy phases of the other.  Ordering: the LDS unit processes a wave's DS instructions in issue order,
+// so a wave's image stores (and image reads) are done when its ds_add arrives; whoever sees the count has them behind it.
+#ifndef NIC_T16_HALFBAR
+#define NIC_T16_HALFBAR 0
+#endif
+#ifndef NIC_T16_SKEW
+#define NIC_T16_SKEW 100
+#endif
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int lane) {
+#if NIC_T16_HALFBAR
+    target += 4u;
+    asm volatile("" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // bounded: every wave of a half runs the same number of barriers, so the count always arrives; the bound only turns a logic
+    // error into wrong numbers (caught by the parity tests) instead of a hung GPU
+    for (int spin = 0; spin < (1 << 16); ++spin) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+#elif NIC_T16_HALFBAR == 0
+    wg_lds_barrier();
+#endif      // NIC_T16_HALFBAR < 0: no barrier at all (timing ablation only: the results are wrong)
+}
+
 // =====================================================================================================
+#ifndef NIC_T16_LB
+#define NIC_T16_LB 512
+#endif
+#ifndef NIC_T16_SB
+#define NIC_T16_SB ((void)0)      // a scheduling barrier between the phases of a round costs 4 %: the compiler overlaps their edges
+#endif
 template <class L, int MODE>
-__global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
+__global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p) {
     using S = Lds16;
     static_assert(L::DIM == 2 && L::CIN == 73, "the 16-sample training kernel is built for the 2D slot layouts");
     static_assert(MODE != MODE_INFER, "training kernel");
     constexpr int LD1 = S::LD1, LD2 = S::LD2, LD3 = S::LD3, LDZ = S::LDZ, LDX = S::LDX;
-    constexpr bool HG0 = (NIC_T16_HOIST & 1) != 0, HG1 = (NIC_T16_HOIST & 2) != 0;
     __shared__ __attribute__((aligned(16))) __bf16 smem16[S::TOTAL];
     lds_bf* const sm = (lds_bf*)smem16;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: scalar registers, scalar branches
 
     // ---------------- prologue: decoder weights -> bf16 hi / lo images (W1 in compact rho order with b1 in the column of the
     // constant-one slot; W2 / W3 columns in position order), per-wave images zeroed
@@ -296,6 +321,9 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);                   // b2 [64] in natural order, b3 [4]
     if (tid < kH) Bs[tid] = p.b[1][tid];
     if (tid >= kH && tid < kH + 4) Bs[tid] = tid - kH < 3 ? p.b[2][tid - kH] : 0.f;
+    lds_u32* const bar_cnt = (lds_u32*)(Bs + kH + 4) + __builtin_amdgcn_readfirstlane(tid >> 8);      // one arrival counter per half
+    if (tid < 2) ((lds_u32*)(Bs + kH + 4))[tid] = 0u;
+    uint32_t bar_target = 0u;
     for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
     __syncthreads();
 
@@ -307,30 +335,42 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
     float accB3[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
     const int T4 = wave & 3, kh = wave >> 2;
     const int to = T4 >> 1, tk = T4 & 1;
-
-    // ---------------- per-lane LDS bases
     lds_bf* const img0 = sm + S::OFF_IMG;
-    lds_bf* const imgw = img0 + wave * S::SPW;
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3, h32 = lane >> 5, cg = (lane >> 4) & 1;
+#ifdef NIC_T16_PRIO
+    if (kh == NIC_T16_PRIO) __builtin_amdgcn_s_setprio(1);       // static priority for one wave of every SIMD pair (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
+#if NIC_T16_HALFBAR
+    if (kh) __builtin_amdgcn_s_sleep(NIC_T16_SKEW);           // the second half starts ~ half a round late (64 cycles per unit)
+#endif
+
+#ifdef NIC_STAMPS
+    unsigned long long stamp_sum[NIC_NPH];
+#pragma unroll
+    for (int i = 0; i < NIC_NPH; ++i) stamp_sum[i] = 0;
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
     // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave); see fused_kernel.hpp
+    // (work units are counted in 32 bits: the host refuses launches with 2^30 or more of them)
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
-    const int64_t n_units = p.n_tiles << p.rg_log2;
-    const int64_t chunk = (((n_units + 7) >> 3) + 7) & ~(int64_t)7;
-    const int64_t t_begin = xcd * chunk;
-    const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
+    const int n_units = (int)p.n_tiles << p.rg_log2;
+    const int chunk = (((n_units + 7) >> 3) + 7) & ~7;
+    const int t_begin = xcd * chunk;
+    const int t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
     const int lstride = nb8 * 8;
-    const int64_t base0 = t_begin + (int64_t)(blockIdx.x >> 3) * 8;
-    const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
+    const int base0 = t_begin + (int)(blockIdx.x >> 3) * 8;
+    const int n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
+    const int tiles_per_crop = (int)p.tiles_per_crop, tiles_main = (int)p.tiles_main;
     const int rounds_unit = (p.niter * p.passes) >> p.rg_log2;
     const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);
     const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || p.rg_log2 == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
 
-    for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
-        const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
+    for (int kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
+        const int base = base0 + (kk < n_my ? kk : 0) * lstride;
         const bool tile_ok = base + wave < t_end;
-        const int64_t unit = tile_ok ? base + wave : t_end - 1;
-        const int64_t tile = unit >> p.rg_log2;
+        const int unit = tile_ok ? base + wave : t_end - 1;
+        const int tile = unit >> p.rg_log2;
         int it_len = rounds_unit, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * rounds_unit;
         if (shift) {
             if (kk == 0) { it_begin += shift; it_len -= shift; }
@@ -339,16 +379,21 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
         // ---------- macro-tile -> this lane's cell (absolute block coordinates) and crop
         int lw = 4;
         int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
-        const int crop = (int)(tile / p.tiles_per_crop);
+        const int crop = tile / tiles_per_crop;
+        GridAcc16 gacc;
+        f32x4 dxacc[4];                                                      // tiles 0..2: the cell's G0 gradient sums (persistent over the rounds)
+        uint32_t blk_off0, blk_off1;
+        CellRaw16 raw;
         {
-            const int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
+            const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
+            const int tt = tile - crop * tiles_per_crop;
             int boff[2];
-            if (p.edge_lw < 0 || tt < p.tiles_main) {
+            if (p.edge_lw < 0 || tt < tiles_main) {
                 boff[1] = tt % p.tiles_y;                 // regular tile: 16 x 1 cells
                 boff[0] = (tt / p.tiles_y) * 16;
             } else {
                 lw = p.edge_lw;                           // edge tile: 2^lw x (16 >> lw) cells
-                boff[1] = (tt - (int)p.tiles_main) * (16 >> lw);
+                boff[1] = (tt - tiles_main) * (16 >> lw);
                 boff[0] = p.full_x * 16;
             }
             const int lc[2] = {n16 & ((1 << lw) - 1), n16 >> lw};
@@ -357,309 +402,316 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
                 org[a] = p.origins[crop * 2 + a];
                 blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
-        }
-        GridAcc16 gacc;
-        f32x4 dxacc[4];                                                      // tiles 0..2: the cell's G0 gradient sums (persistent over the rounds)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) gacc.g1[i] = 0.f;
+            for (int i = 0; i < 12; ++i) gacc.g1[i] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dxacc[t] = f32x4(0.f);
-        uint32_t blk_off0, blk_off1;
-        CellRaw16 raw;
-        {
+            for (int t = 0; t < 4; ++t) dxacc[t] = f32x4(0.f);
             const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, 0};
             cell_offsets<L>(p, qb, blk_off0, blk_off1);
-            gather_cell16<float>(p, blk_off0, blk_off1, g, raw, HG0, HG1);
+            gather_cell16(p, blk_off0, blk_off1, g, raw);
         }
+        STAMP(12);   // macro-tile setup, raw gathers issued
 
         for (int it = it_begin; it < it_begin + it_len; ++it) {
-            // ---------- per-lane LDS bases, opaque inside the loop (see fused_kernel.hpp)
-            lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
-            lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 64 + 4 * g));
-            lds_cbf* const w2_row = opaque((lds_cbf*)(sm + S::OFF_W2 + n16 * LD2 + 8 * g));
-            lds_cbf* const w3_row = opaque((lds_cbf*)(sm + S::OFF_W3 + (n16 < 3 ? n16 : 3) * LD3 + 8 * g));
-            lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
-            lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + (4 * g + q4) * LD2 + 8 * p4));
-            lds_cbf* const w3_tr = opaque((lds_cbf*)(sm + S::OFF_W3 + q4 * LD3 + 8 * p4));
-            lds_cf* const b2_row = opaque(Bs + 4 * g);
-            lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);                 // fragment stores: row n, columns 32 s + 8 g
-            lds_bf* const a1_st = opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
-            lds_bf* const x_st = opaque(imgw + S::OFF_X + n16 * LDX + 8 * g);
-            lds_bf* const x_st2 = opaque(imgw + S::OFF_X + n16 * LDX + 64 + 4 * g);
-            lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
-            // 4x4x4 operands (own samples): B = column `lane` of samples 4 q' + r; A = dZ3[c = lane & 3][those samples]
-            lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + 4 * q4 * LDZ + 16 * g + 4 * p4));
-            lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (lane & 3) * 16));
-            // 32x32x16 weight-gradient operands: samples 4 q' + 2 (lane >> 5) + rd of a source wave, columns 32 tile + 16 cg + 4 p4
-            lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
-            lds_cbf* const a1_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_A1 + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
-            lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_X + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
-            // 16x16x32 tail operands: quarter G reads source wave 4 kh + 2 uu + (G >> 1), samples 4 q' + 2 (G & 1) + rd
-            lds_cbf* const dz_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + (4 * q4 + 2 * (g & 1)) * LDZ + 16 * T4 + 4 * p4));
-            lds_cbf* const x_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + S::OFF_X + (4 * q4 + 2 * (g & 1)) * LDX + 64 + 4 * p4));
-
-            // ---------- which sample does this lane own in this round
-            bool valid = tile_ok;
-            int64_t n;
-            int q[3] = {0, 0, 0};
-            {
-                const int m1 = (1 << p.lm) - 1;
-                const int pass = it >> (p.lm * 2), its = it & (p.niter - 1);
-                const int j[2] = {its >> p.lm, its & m1};
-                const int ext[2] = {p.d.extent[0], p.d.extent[1]};
-                int idx[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int i = (blk[a] << p.lm) + j[a] - org[a];
-                    valid = valid && i >= 0 && i < ext[a];
-                    idx[a] = i < 0 ? 0 : (i >= ext[a] ? ext[a] - 1 : i);
-                    q[a] = org[a] + idx[a];
-                }
-                n = ((int64_t)crop * p.passes + pass) * p.n_per_crop + (int64_t)idx[0] * ext[1] + idx[1];
-            }
-            // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
-            float tgt[3] = {0.f, 0.f, 0.f};
-            if (MODE == MODE_TRAIN_IMG) {
-                const int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (p.timg_u8) {
-                        const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
-                        const float t0 = mul_rn(u, p.timg_rcp);
-                        tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
-                    } else {
-                        tgt[c] = (reinterpret_cast<const float*>(p.timg) + c * p.timg_cs)[off];
-                    }
-                }
-            } else {
-                const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
-            }
-            // ---------- input slots
-            float xs[20];
-            EncCtx cx;
-            encode16<L, HG0, HG1>(p, q, g, xs, cx, raw);
-            add_noise16<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
-
-            // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
-            f32x4 a1[4], d1[4];
-            {
-                f32x4 z[4] = {f32x4(0.f), f32x4(0.f), f32x4(0.f), f32x4(0.f)};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    Frag2 af[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        af[t].hi = ld_frag(&w1_row[16 * t * LD1 + 32 * s]);
-                        af[t].lo = ld_frag(&w1_row[S::W1LO + 16 * t * LD1 + 32 * s]);
-                    }
-                    // slots 8s .. 8s+7 (slot 15 is the zero slot)
-                    const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6],
-                                         s == 0 ? xs[7] : 0.f};
-                    const Frag2 bf = split8(xv);
-                    st_frag(&x_st[32 * s], bf.hi);
-                    st_frag(&x_st[S::XLO + 32 * s], bf.lo);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
-                }
-                {   // k-step 2: slots 16..19, compact columns 64 + 4 g + j
-                    Frag2 af[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        af[t].hi = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]));
-                        af[t].lo = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[S::W1LO + 16 * t * LD1]));
-                    }
-                    const float xv[8] = {xs[15], xs[16], xs[17], xs[18], 0.f, 0.f, 0.f, 0.f};
-                    const Frag2 bf = split8(xv);
-                    const s16x8 bh = __builtin_bit_cast(s16x8, bf.hi), bl = __builtin_bit_cast(s16x8, bf.lo);
-                    *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
-                    *reinterpret_cast<lds_s16x4*>(x_st2 + S::XLO) = s16x4{bl[0], bl[1], bl[2], bl[3]};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------- layer 2
-            f32x4 a2[4], d2[4];
-            {
-                f32x4 z[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) z[t] = ld4(&b2_row[16 * t]);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    Frag2 af[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        af[t].hi = ld_frag(&w2_row[16 * t * LD2 + 32 * s]);
-                        af[t].lo = ld_frag(&w2_row[S::W2LO + 16 * t * LD2 + 32 * s]);
-                    }
-                    const Frag2 bf = split_pair(a1[2 * s], a1[2 * s + 1]);
-                    st_frag(&a1_st[32 * s], bf.hi);
-                    st_frag(&a1_st[S::DZLO + 32 * s], bf.lo);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) z[t] = mfma16_split(af[t], bf, z[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
-            // the a2 image of dW3 (the DZ region is free until dZ2 is stored)
-            float yv[3];
-            {
-                f32x4 z3 = f32x4(0.f);
-                Frag2 af[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    af[s].hi = ld_frag(&w3_row[32 * s]);
-                    af[s].lo = ld_frag(&w3_row[S::W3LO + 32 * s]);
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const Frag2 bf = split_pair(a2[2 * s], a2[2 * s + 1]);
-                    st_frag(&dz_st[32 * s], bf.hi);
-                    st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
-                    z3 = mfma16_split(af[s], bf, z3);
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[kH + c]);
-            }
-            const bool own = valid && g == 0;
-            if (p.y != nullptr && own) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------- dZ3
+            // ================= forward =================
+            f32x4 a1[4], d1[4], a2[4], d2[4];
             float dz3[3];
+            float kx1, ky1;                                                   // G1 interpolation fractions of the sample (for the G1 gradient weights)
+            {
+                const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
+                // ---------- which sample does this lane own in this round
+                bool valid = tile_ok;
+                int64_t n;
+                int q[3] = {0, 0, 0};
+                {
+                    const int m1 = (1 << p.lm) - 1;
+                    const int pass = it >> (p.lm * 2), its = it & (p.niter - 1);
+                    const int j[2] = {its >> p.lm, its & m1};
+                    const int ext[2] = {p.d.extent[0], p.d.extent[1]};
+                    int idx[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float gr;
-                if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
-                    const float diff = own ? yv[c] - tgt[c] : 0.f;
-                    accLoss += diff * diff;
-                    gr = p.grad_scale * diff;
-                } else {
-                    gr = own ? tgt[c] : 0.f;
+                    for (int a = 0; a < 2; ++a) {
+                        const int i = (blk[a] << p.lm) + j[a] - org[a];
+                        valid = valid && i >= 0 && i < ext[a];
+                        idx[a] = i < 0 ? 0 : (i >= ext[a] ? ext[a] - 1 : i);
+                        q[a] = org[a] + idx[a];
+                    }
+                    n = ((int64_t)crop * p.passes + pass) * p.n_per_crop + (int64_t)idx[0] * ext[1] + idx[1];
                 }
-                dz3[c] = gr * yv[c] * (1.0f - yv[c]);
-                accB3[c] += dz3[c];
-            }
-            if (g == 0) {
+                // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
+                float tgt[3] = {0.f, 0.f, 0.f};
+                if (MODE == MODE_TRAIN_IMG) {
+                    const int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (p.timg_u8) {
+                            const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                            const float t0 = mul_rn(u, p.timg_rcp);
+                            tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
+                        } else {
+                            tgt[c] = (reinterpret_cast<const float*>(p.timg) + c * p.timg_cs)[off];
+                        }
+                    }
+                } else {
+                    const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
+                }
+                // ---------- input slots
+                float xs[20];
+                {
+                    EncCtx cx;
+                    encode16<L>(p, q, g, xs, cx, raw);
+                    kx1 = cx.kx; ky1 = cx.ky;
+                    add_noise16<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+                }
+                STAMP(0);    // coordinates, blend, PE, noise
+                NIC_T16_SB;
+                lds_bf* const imgw = img0 + wave * S::SPW;
+                // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
+                {
+                    lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LD1 + 8 * g));                    // W1 and W2 (LD1 == LD2): row n16, columns 8 g ..
+                    lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 64 + 4 * g));
+                    lds_bf* const x_st = opaque(imgw + S::OFF_X + n16 * LDX + 8 * g);                     // fragment stores: row n, columns 32 s + 8 g
+                    lds_bf* const x_st2 = opaque(imgw + S::OFF_X + n16 * LDX + 64 + 4 * g);
+                    f32x4 z[4];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        // slots 8s .. 8s+7 (slot 15 is the zero slot)
+                        const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6],
+                                             s == 0 ? xs[7] : 0.f};
+                        const Frag2 bf = split8(xv);
+                        st_frag(&x_st[32 * s], bf.hi);
+                        st_frag(&x_st[S::XLO + 32 * s], bf.lo);
+                        auto la = [&](int t) {
+                            Frag2 a;
+                            a.hi = ld_frag(&w_row[S::OFF_W1 + 16 * t * LD1 + 32 * s]);
+                            a.lo = ld_frag(&w_row[S::OFF_W1 + S::W1LO + 16 * t * LD1 + 32 * s]);
+                            return a;
+                        };
+                        if (s == 0) kstep16<4, true>(z, bf, la);
+                        else kstep16<4>(z, bf, la);
+                    }
+                    {   // k-step 2: slots 16..19, compact columns 64 + 4 g + j
+                        const float xv[8] = {xs[15], xs[16], xs[17], xs[18], 0.f, 0.f, 0.f, 0.f};
+                        const Frag2 bf = split8(xv);
+                        const s16x8 bh = __builtin_bit_cast(s16x8, bf.hi), bl = __builtin_bit_cast(s16x8, bf.lo);
+                        *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
+                        *reinterpret_cast<lds_s16x4*>(x_st2 + S::XLO) = s16x4{bl[0], bl[1], bl[2], bl[3]};
+                        kstep16<4>(z, bf, [&](int t) {
+                            Frag2 a;
+                            a.hi = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]));
+                            a.lo = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[S::W1LO + 16 * t * LD1]));
+                            return a;
+                        });
+                    }
+                    // (tile-outer order - the GELU of row tile t beside the MFMAs of tile t + 1 - measured 3.5 % slower: 8 more registers
+                    //  spill, and the packed-fp32 GELU chains stop the matrix pipe rather than run beside it)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
+                    NIC_T16_SB;
+                    // ---------- layer 2
+                    lds_cf* const b2_row = opaque(Bs + 4 * g);
+                    lds_bf* const a1_st = opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = ld4(&b2_row[16 * t]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const Frag2 bf = split_pair(a1[2 * s], a1[2 * s + 1]);
+                        st_frag(&a1_st[32 * s], bf.hi);
+                        st_frag(&a1_st[S::DZLO + 32 * s], bf.lo);
+                        kstep16<4>(z, bf, [&](int t) {
+                            Frag2 a;
+                            a.hi = ld_frag(&w_row[S::OFF_W2 + 16 * t * LD2 + 32 * s]);
+                            a.lo = ld_frag(&w_row[S::OFF_W2 + S::W2LO + 16 * t * LD2 + 32 * s]);
+                            return a;
+                        });
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
+                }
+                NIC_T16_SB;
+                // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
+                // the a2 image of dW3 (the DZ region is free until dZ2 is stored)
+                float yv[3];
+                {
+                    lds_cbf* const w3_row = opaque((lds_cbf*)(sm + S::OFF_W3 + (n16 < 3 ? n16 : 3) * LD3 + 8 * g));
+                    lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);
+                    f32x4 z3;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        Frag2 af;
+                        af.hi = ld_frag(&w3_row[32 * s]);
+                        af.lo = ld_frag(&w3_row[S::W3LO + 32 * s]);
+                        const Frag2 bf = split_pair(a2[2 * s], a2[2 * s + 1]);
+                        st_frag(&dz_st[32 * s], bf.hi);
+                        st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
+                        z3 = mfma16_split(af, bf, s == 0 ? f32x4(0.f) : z3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[kH + c]);
+                }
+                STAMP(1);    // layers 1 - 3 with their image stores and GELUs
+                const bool own = valid && g == 0;
+                if (p.y != nullptr && own) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+                }
+                // ---------- dZ3
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const __bf16 hi = (__bf16)dz3[c];
-                    d3_st[c * 16] = hi;
-                    d3_st[64 + c * 16] = (__bf16)(dz3[c] - (float)hi);
+                    float gr;
+                    if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
+                        const float diff = own ? yv[c] - tgt[c] : 0.f;
+                        accLoss += diff * diff;
+                        gr = p.grad_scale * diff;
+                    } else {
+                        gr = own ? tgt[c] : 0.f;
+                    }
+                    dz3[c] = gr * yv[c] * (1.0f - yv[c]);
+                    accB3[c] += dz3[c];
+                }
+                if (g == 0) {
+                    lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const __bf16 hi = (__bf16)dz3[c];
+                        d3_st[c * 16] = hi;
+                        d3_st[64 + c * 16] = (__bf16)(dz3[c] - (float)hi);
+                    }
                 }
             }
             wave_lds_fence();
-            // ---------- dW3[c][pos = lane] += sum_n dZ3[c][n] a2[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
-            {
-                s16x4 bh[4], bl[4], ah[4], al[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    bh[r] = tr4(&dz_b44[r * LDZ]);
-                    bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
-                    ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
-                    al[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[64 + 4 * r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    accW3q = mfma4_bf(al[r], bh[r], accW3q);
-                    accW3q = mfma4_bf(ah[r], bl[r], accW3q);
-                    accW3q = mfma4_bf(ah[r], bh[r], accW3q);
-                }
-            }
-            // ---------- dA2 = W3^T dZ3 (k = c: quarter 0 carries dZ3 in elements 0..2, everything else is zero), dZ2 = dA2 * gelu'(Z2)
-            f32x4 dz2[4];
-            {
-                const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
-                const Frag2 bf = split8(dzv);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const s16x4 ahh = tr4(&w3_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
-                    const s16x4 all = tr4(&w3_tr[S::W3LO + 32 * (t >> 1) + 4 * (t & 1)]);
-                    Frag2 af;
-                    af.hi = join8(ahh, ahh);
-                    af.lo = join8(all, all);
-                    dz2[t] = mfma16_split(af, bf, f32x4(0.f)) * d2[t];
-                }
-            }
-            wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
-            // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are the dZ2 image of the weight-gradient product
+            NIC_T16_SB;
+            // ================= backward =================
             f32x4 dz1[4];
             {
-                f32x4 acc[4] = {f32x4(0.f), f32x4(0.f), f32x4(0.f), f32x4(0.f)};
+                const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
+                lds_bf* const imgw = img0 + wave * S::SPW;
+                // 4x4x4 operands (own samples): B = column `lane` of samples 4 q' + r; A = dZ3[c = lane & 3][those samples]
+                lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                // ---------- dW3[c][pos = lane] += sum_n dZ3[c][n] a2[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
+                {
+                    lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (ln & 3) * 16));
+                    s16x4 bh[4], bl[4], ah[4], al[4];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    Frag2 af[4];
+                    for (int r = 0; r < 4; ++r) {
+                        bh[r] = tr4(&dz_b44[r * LDZ]);
+                        bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
+                        ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
+                        al[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[64 + 4 * r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accW3q = mfma4_bf(al[r], bh[r], accW3q);
+                        accW3q = mfma4_bf(ah[r], bl[r], accW3q);
+                        accW3q = mfma4_bf(ah[r], bh[r], accW3q);
+                    }
+                }
+                // ---------- dA2 = W3^T dZ3 (k = c: quarter 0 carries dZ3 in elements 0..2, everything else is zero), dZ2 = dA2 * gelu'(Z2)
+                f32x4 dz2[4];
+                {
+                    lds_cbf* const w3_tr = opaque((lds_cbf*)(sm + S::OFF_W3 + q4 * LD3 + 8 * p4));
+                    const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const Frag2 bf = split8(dzv);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int co = 32 * (t >> 1) + 4 * (t & 1);
-                        af[t].hi = join8(tr4(&w2_tr[32 * s * LD2 + co]), tr4(&w2_tr[(32 * s + 16) * LD2 + co]));
-                        af[t].lo = join8(tr4(&w2_tr[S::W2LO + 32 * s * LD2 + co]), tr4(&w2_tr[S::W2LO + (32 * s + 16) * LD2 + co]));
+                        const s16x4 ahh = tr4(&w3_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
+                        const s16x4 all = tr4(&w3_tr[S::W3LO + 32 * (t >> 1) + 4 * (t & 1)]);
+                        Frag2 af;
+                        af.hi = join8(ahh, ahh);
+                        af.lo = join8(all, all);
+                        dz2[t] = mfma16_split(af, bf, f32x4(0.f)) * d2[t];
                     }
-                    const Frag2 bf = split_pair(dz2[2 * s], dz2[2 * s + 1]);
-                    st_frag(&dz_st[32 * s], bf.hi);
-                    st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = mfma16_split(af[t], bf, acc[t]);
                 }
+                STAMP(2);    // dZ3 image, dW3, dA2
+                wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
+                NIC_T16_SB;
+                // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are the dZ2 image of the weight-gradient product
+                {
+                    lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + (4 * g + q4) * LD2 + 8 * p4));
+                    lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);
+                    f32x4 acc[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dz1[t] = acc[t] * d1[t];
+                    for (int s = 0; s < 2; ++s) {
+                        const Frag2 bf = split_pair(dz2[2 * s], dz2[2 * s + 1]);
+                        st_frag(&dz_st[32 * s], bf.hi);
+                        st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
+                        auto la = [&](int t) {
+                            const int co = 32 * (t >> 1) + 4 * (t & 1);
+                            Frag2 a;
+                            a.hi = join8(tr4(&w2_tr[32 * s * LD2 + co]), tr4(&w2_tr[(32 * s + 16) * LD2 + co]));
+                            a.lo = join8(tr4(&w2_tr[S::W2LO + 32 * s * LD2 + co]), tr4(&w2_tr[S::W2LO + (32 * s + 16) * LD2 + co]));
+                            return a;
+                        };
+                        if (s == 0) kstep16<4, true>(acc, bf, la);
+                        else kstep16<4>(acc, bf, la);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dz1[t] = acc[t] * d1[t];
+                }
+                wave_lds_fence();
+                // ---------- db2[pos = lane] += sum_n dZ2[pos][n]: 4x4x4 MFMAs against a block of ones
+                {
+                    const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+                    s16x4 bh[4], bl[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
+                        bh[r] = tr4(&dz_b44[r * LDZ]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accB2q = mfma4_bf(ones, bl[r], accB2q);
+                        accB2q = mfma4_bf(ones, bh[r], accB2q);
+                    }
+                }
             }
-            wave_lds_fence();
-            // ---------- db2[pos = lane] += sum_n dZ2[pos][n]: 4x4x4 MFMAs against a block of ones
-            {
-                const s16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
-                s16x4 bh[4], bl[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    bl[r] = tr4(&dz_b44[S::DZLO + r * LDZ]);
-                    bh[r] = tr4(&dz_b44[r * LDZ]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    accB2q = mfma4_bf(ones, bl[r], accB2q);
-                    accB2q = mfma4_bf(ones, bh[r], accB2q);
-                }
-            }
-            wg_lds_barrier();
+            STAMP(3);    // dA1 (+ dZ2 image), db2
+            half_barrier(bar_cnt, bar_target, lane);
+            STAMP(4);    // wait at barrier 1
+            NIC_T16_SB;
             // ---------- dW2 tile (to, tk) += sum over the samples of waves 4 kh .. 4 kh + 3 of dZ2[o][n] a1[k][n]
+            {
+                const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
+                // 32x32x16 operands: samples 4 q' + 2 (lane >> 5) + rd of a source wave, columns 32 tile + 16 cg + 4 p4
+                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+                lds_cbf* const a1_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_A1 + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                Frag2 af, bf;
-                af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
-                bf.lo = join8(tr4(&a1_t32[v * S::SPW + S::DZLO]), tr4(&a1_t32[v * S::SPW + S::DZLO + LDZ]));
-                af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
-                bf.hi = join8(tr4(&a1_t32[v * S::SPW]), tr4(&a1_t32[v * S::SPW + LDZ]));
-                accW2 = mfma_split(af, bf, accW2);
+                for (int v = 0; v < 4; ++v) {
+                    Frag2 af, bf;
+                    af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                    bf.lo = join8(tr4(&a1_t32[v * S::SPW + S::DZLO]), tr4(&a1_t32[v * S::SPW + S::DZLO + LDZ]));
+                    af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
+                    bf.hi = join8(tr4(&a1_t32[v * S::SPW]), tr4(&a1_t32[v * S::SPW + LDZ]));
+                    accW2 = mfma_split(af, bf, accW2);
+                }
             }
-            wg_lds_barrier();                                              // everyone is done reading dZ2 before dZ1 replaces it
+            STAMP(5);    // dW2 MFMAs
+            half_barrier(bar_cnt, bar_target, lane);                       // everyone is done reading dZ2 before dZ1 replaces it
+            STAMP(6);    // wait at barrier 2
+            NIC_T16_SB;
             // ---------- dX = W1^T dZ1 for the grid slots (tiles 0..3 = slots 0..15); the split dZ1 fragments are the dZ1 image.
             // Tiles 0..2 (the G0 channels) keep their running sums over the rounds in the product's C operand.
             {
+                const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
+                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
+                lds_bf* const dz_st = opaque(img0 + wave * S::SPW + n16 * LDZ + 8 * g);
                 dxacc[3] = f32x4(0.f);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    Frag2 af[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int co = 32 * (t >> 1) + 4 * (t & 1);
-                        af[t].hi = join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
-                        af[t].lo = join8(tr4(&w1_tr[S::W1LO + 32 * s * LD1 + co]), tr4(&w1_tr[S::W1LO + (32 * s + 16) * LD1 + co]));
-                    }
                     const Frag2 bf = split_pair(dz1[2 * s], dz1[2 * s + 1]);
                     st_frag(&dz_st[32 * s], bf.hi);
                     st_frag(&dz_st[S::DZLO + 32 * s], bf.lo);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dxacc[t] = mfma16_split(af[t], bf, dxacc[t]);
+                    kstep16<4>(dxacc, bf, [&](int t) {
+                        const int co = 32 * (t >> 1) + 4 * (t & 1);
+                        Frag2 a;
+                        a.hi = join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
+                        a.lo = join8(tr4(&w1_tr[S::W1LO + 32 * s * LD1 + co]), tr4(&w1_tr[S::W1LO + (32 * s + 16) * LD1 + co]));
+                        return a;
+                    });
                 }
-                const G1Factors gf = g1_factors<2>(p.d.g1_weight_mode, cx.kx, cx.ky, 0.f);
+                const G1Factors gf = g1_factors<2>(p.d.g1_weight_mode, kx1, ky1, 0.f);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const float w = g1_corner_factor<2>(gf, c4);
@@ -667,33 +719,47 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
                     for (int cc = 0; cc < 3; ++cc) gacc.g1[c4 * 3 + cc] = fmaf(dxacc[3][cc], w, gacc.g1[c4 * 3 + cc]);
                 }
             }
-            wg_lds_barrier();
-            // ---------- dW1: columns 0..63 as the 32x32 tile (to, tk) over the same four source waves ...
+            STAMP(7);    // dX (+ dZ1 image), grid-gradient accumulation
+            half_barrier(bar_cnt, bar_target, lane);
+            STAMP(8);    // wait at barrier 3
+            NIC_T16_SB;
+            {
+                const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
+                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+                lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_X + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
+                // ---------- dW1: columns 0..63 as the 32x32 tile (to, tk) over the same four source waves ...
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                Frag2 af, bf;
-                af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
-                bf.lo = join8(tr4(&x_t32[v * S::SPW + S::XLO]), tr4(&x_t32[v * S::SPW + S::XLO + LDX]));
-                af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
-                bf.hi = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
-                accW1 = mfma_split(af, bf, accW1);
-            }
-            // ... columns 64..79 as a 16x16 tile (rows 16 T4 ..): two k-steps of 32 samples (two source waves each)
+                for (int v = 0; v < 4; ++v) {
+                    Frag2 af, bf;
+                    af.hi = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                    bf.lo = join8(tr4(&x_t32[v * S::SPW + S::XLO]), tr4(&x_t32[v * S::SPW + S::XLO + LDX]));
+                    af.lo = join8(tr4(&dz_t32[v * S::SPW + S::DZLO]), tr4(&dz_t32[v * S::SPW + S::DZLO + LDZ]));
+                    bf.hi = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
+                    accW1 = mfma_split(af, bf, accW1);
+                }
+                // ... columns 64..79 as a 16x16 tile (rows 16 T4 ..): two k-steps of 32 samples; quarter G reads source wave
+                // 4 kh + 2 uu + (G >> 1), samples 4 q' + 2 (G & 1) + rd
+                lds_cbf* const dz_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + (4 * q4 + 2 * (g & 1)) * LDZ + 16 * T4 + 4 * p4));
+                lds_cbf* const x_t16 = opaque((lds_cbf*)(img0 + (4 * kh + (g >> 1)) * S::SPW + S::OFF_X + (4 * q4 + 2 * (g & 1)) * LDX + 64 + 4 * p4));
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                Frag2 af, bf;
-                af.hi = join8(tr4(&dz_t16[2 * uu * S::SPW]), tr4(&dz_t16[2 * uu * S::SPW + LDZ]));
-                af.lo = join8(tr4(&dz_t16[2 * uu * S::SPW + S::DZLO]), tr4(&dz_t16[2 * uu * S::SPW + S::DZLO + LDZ]));
-                bf.hi = join8(tr4(&x_t16[2 * uu * S::SPW]), tr4(&x_t16[2 * uu * S::SPW + LDX]));
-                bf.lo = join8(tr4(&x_t16[2 * uu * S::SPW + S::XLO]), tr4(&x_t16[2 * uu * S::SPW + S::XLO + LDX]));
-                accT = mfma16_split(af, bf, accT);
+                for (int uu = 0; uu < 2; ++uu) {
+                    Frag2 af, bf;
+                    af.hi = join8(tr4(&dz_t16[2 * uu * S::SPW]), tr4(&dz_t16[2 * uu * S::SPW + LDZ]));
+                    af.lo = join8(tr4(&dz_t16[2 * uu * S::SPW + S::DZLO]), tr4(&dz_t16[2 * uu * S::SPW + S::DZLO + LDZ]));
+                    bf.hi = join8(tr4(&x_t16[2 * uu * S::SPW]), tr4(&x_t16[2 * uu * S::SPW + LDX]));
+                    bf.lo = join8(tr4(&x_t16[2 * uu * S::SPW + S::XLO]), tr4(&x_t16[2 * uu * S::SPW + S::XLO + LDX]));
+                    accT = mfma16_split(af, bf, accT);
+                }
             }
-            wg_lds_barrier();                      // all reads of dZ1 / X done before the next round overwrites them
+            STAMP(9);    // dW1 MFMAs
+            half_barrier(bar_cnt, bar_target, lane);   // all reads of dZ1 / X done before the next round overwrites them
+            STAMP(10);   // wait at barrier 4
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
         {
-            combine_g1_lanes16(gacc, blk_off1, blk, lane, lw);
+            const int ln = opaque_i(lane), g = ln >> 4;
+            combine_g1_lanes16(gacc, blk_off1, blk, ln, lw);
             bool flush = true;
             if (NIC_GROUP_SUM && p.rg_log2 > 0) {                          // launch-uniform: groups of one macro-tile sit in one workgroup
                 lds_f* const reg0 = (lds_f*)img0;
@@ -701,52 +767,68 @@ __global__ void __launch_bounds__(512) fused_train16_kernel(FusedParams p) {
                 static_assert(24 * 64 <= REGION, "group-sum scratch");
                 int leader = wave;
                 if (tile_ok)
-                    for (int w = wave - 1; w >= 0; --w)
+                    for (int w = wave - 1; w >= 4 * kh; --w)
                         if (((base + w) >> p.rg_log2) == tile) leader = w;
                 if (leader != wave) {
-                    lds_f* const mine = opaque(reg0 + wave * REGION + lane);
+                    lds_f* const mine = opaque(reg0 + wave * REGION + ln);
 #pragma unroll
                     for (int i = 0; i < 12; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
 #pragma unroll
                     for (int i = 0; i < 12; ++i) mine[(12 + i) * 64] = gacc.g1[i];
                 }
-                wg_lds_barrier();
+                half_barrier(bar_cnt, bar_target, lane);
                 if (leader == wave && tile_ok) {
-                    for (int w = wave + 1; w < 8; ++w) {
+                    for (int w = wave + 1; w < 4 * kh + 4; ++w) {
                         if (base + w >= t_end || ((base + w) >> p.rg_log2) != tile) break;
-                        lds_cf* const theirs = opaque(reg0 + w * REGION + lane);
+                        lds_cf* const theirs = opaque(reg0 + w * REGION + ln);
 #pragma unroll
                         for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] += theirs[i * 64];
 #pragma unroll
                         for (int i = 0; i < 12; ++i) gacc.g1[i] += theirs[(12 + i) * 64];
                     }
                 }
-                wg_lds_barrier();
+                half_barrier(bar_cnt, bar_target, lane);
                 flush = leader == wave;
-                // the scratch overlays the images: zero what was written (rows of D3 / padding are assumed zero by nobody, but the
-                // images are rewritten before they are read in every round - nothing to restore)
             }
+#ifdef NIC_T16_NOFLUSH
+            flush = false;                                                  // timing ablation only
+#endif
             if (flush) {
-                const uint32_t voff0 = blk_off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0);
+                // one predicate per lane and grid instead of one per value: a lane whose 12 sums are all exact zeros (cell outside the
+                // crop; G1 sums handed to the partner lane) issues nothing - 2 exec-mask regions per flush instead of 24
+                const uint32_t pb0 = (uint32_t)p.g0.plane * 4u, pb1 = (uint32_t)p.g1.plane * 4u;
+                uint32_t nz0 = 0u, nz1 = 0u;
 #pragma unroll
                 for (int c = 0; c < kC; ++c) {
-                    const float v = dxacc[c >> 2][c & 3];
-                    float* plane = p.g0_grad + (int64_t)c * p.g0.plane;
-                    if (v != 0.f) atomicAdd(plane + voff0, v);
+                    nz0 |= __builtin_bit_cast(uint32_t, dxacc[c >> 2][c & 3]);
+                    nz1 |= __builtin_bit_cast(uint32_t, gacc.g1[c]);
                 }
+                if ((nz0 << 1) != 0u) {
+                    uint32_t ob = (blk_off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0)) * 4u;
+                    char* gbase = reinterpret_cast<char*>(p.g0_grad);
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const uint32_t voff = blk_off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+                    for (int c = 0; c < kC; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), dxacc[c >> 2][c & 3]);
+                }
+                if ((nz1 << 1) != 0u) {
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        const float v = gacc.g1[c4 * 3 + cc];
-                        float* plane = p.g1_grad + (int64_t)cc * p.g1.plane;
-                        if (v != 0.f) atomicAdd(plane + voff, v);
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        uint32_t ob = (blk_off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0)) * 4u + (uint32_t)(3 * g) * pb1;
+                        char* gbase = reinterpret_cast<char*>(p.g1_grad);
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), gacc.g1[c4 * 3 + cc]);
                     }
                 }
             }
         }
+        STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
+#ifdef NIC_STAMPS
+    if (lane == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 8 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
+#pragma unroll
+        for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
 
     // ---------------- one record per workgroup
     float* rec = p.partials + (int64_t)blockIdx.x * S::REC;

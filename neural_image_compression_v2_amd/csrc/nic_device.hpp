@@ -221,6 +221,17 @@ __device__ __forceinline__ float noise_from_byte(const NoiseSrc& ns, uint32_t wo
 __device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& b, int i) {
     return noise_from_byte(ns, block_word(b, (i >> 2) & 3), i & 3);
 }
+// 2D layouts (Cin = 73): 20 six-bit fields per generator block, five per word (bits 6j .. 6j+5 of word f / 5, j = f % 5):
+// u6 -> ((u6 + 1/2) / 64 - 1/2) * 2^-bits (uniform on a 2^-6 lattice of the quantisation step, zero mean).  A sample's 73 channels
+// take FOUR blocks, one per G0 corner q: block q holds corner q's 12 channels (fields 0..11), G1 channels 3q..3q+2 (12..14), PE rows
+// 3q..3q+2 (15..17) and, for q = 0, the LOD channel (18) - a quarter of the 16-sample kernel's lanes, or one of the two corners of
+// a lane half of the 32-sample kernels, runs exactly the blocks it consumes (the byte-per-value numbering needed 6 block
+// evaluations per sample, 8 on the 16-sample kernel; the generator is ~ 170 vector instructions per block).
+__device__ __forceinline__ float noise_field(const NoiseSrc& ns, const U4& b, int f) {
+    const uint32_t w = block_word(b, f / 5);
+    const float u = (float)((w >> (6 * (f % 5))) & 63u);                                 // v_bfe_u32 + v_cvt_f32_u32
+    return ((u + 0.5f) * (1.0f / 64.0f) - 0.5f) * ns.scale;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Grid addressing.  Tensor [C, (Z,) Y, X] (fp_def.py:54,76), per-axis node counts in (x, y, z) order.
