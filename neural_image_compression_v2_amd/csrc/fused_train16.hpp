@@ -282,6 +282,13 @@ __device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int
 #ifndef NIC_T16_SB
 #define NIC_T16_SB ((void)0)      // a scheduling barrier between the phases of a round costs 4 %: the compiler overlaps their edges
 #endif
+// NIC_T16_ALTPRIO: the two waves of a SIMD take turns at priority 1, phase by phase (the arbiter otherwise always prefers the older
+// wave, which then idles at the next barrier while the younger one runs alone)
+#ifdef NIC_T16_ALTPRIO
+#define T16_PRIO(ph) do { if (((ph) + kh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#else
+#define T16_PRIO(ph) do { } while (0)
+#endif
 template <class L, int MODE>
 __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p) {
     using S = Lds16;
@@ -466,6 +473,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     add_noise16<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
                 }
                 STAMP(0);    // coordinates, blend, PE, noise
+                T16_PRIO(1);
                 NIC_T16_SB;
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
@@ -552,6 +560,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[kH + c]);
                 }
                 STAMP(1);    // layers 1 - 3 with their image stores and GELUs
+                T16_PRIO(2);
                 const bool own = valid && g == 0;
                 if (p.y != nullptr && own) {
 #pragma unroll
@@ -670,6 +679,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             STAMP(3);    // dA1 (+ dZ2 image), db2
             half_barrier(bar_cnt, bar_target, lane);
             STAMP(4);    // wait at barrier 1
+            T16_PRIO(3);
             NIC_T16_SB;
             // ---------- dW2 tile (to, tk) += sum over the samples of waves 4 kh .. 4 kh + 3 of dZ2[o][n] a1[k][n]
             {
@@ -690,6 +700,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             STAMP(5);    // dW2 MFMAs
             half_barrier(bar_cnt, bar_target, lane);                       // everyone is done reading dZ2 before dZ1 replaces it
             STAMP(6);    // wait at barrier 2
+            T16_PRIO(4);
             NIC_T16_SB;
             // ---------- dX = W1^T dZ1 for the grid slots (tiles 0..3 = slots 0..15); the split dZ1 fragments are the dZ1 image.
             // Tiles 0..2 (the G0 channels) keep their running sums over the rounds in the product's C operand.
@@ -754,6 +765,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             STAMP(9);    // dW1 MFMAs
             half_barrier(bar_cnt, bar_target, lane);   // all reads of dZ1 / X done before the next round overwrites them
             STAMP(10);   // wait at barrier 4
+            T16_PRIO(0);
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
