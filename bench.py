@@ -176,6 +176,9 @@ def main():
                          "image once per step and the whole gradient bucket (31 MB) is all-reduced")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
+    ap.add_argument("--workload", default="4k", choices=["4k", "lut33", "vol64", "vol128", "video", "default", "fits8"],
+                    help="4k (default): BASELINE configs[1], the headline; the others: bench_workloads.py (configs 3 - 5 and the reference's default "
+                         "step, one GPU, same JSON shape - records for profiles/, the driver runs the default only)")
     ap.add_argument("--launch-check", action="store_true",
                     help="plumbing check of the N-rank launch (tests, no GPU): ranks rendezvous over gloo, sum their ranks, rank 0 prints a JSON line")
     args = ap.parse_args()
@@ -199,6 +202,12 @@ def main():
         dist.destroy_process_group()
         return
 
+    if args.workload != "4k":
+        if world != 1:
+            ap.error("--workload runs on one GPU")
+        import bench_workloads
+        bench_workloads.run(args)
+        return
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -1,0 +1,232 @@
+"""`python bench.py --workload NAME`: the BASELINE.json configurations beyond the headline 4K fit, one GPU, same JSON line shape
+(Mvoxels/s or Mpixels/s of one training step = fused fwd + bwd, plus Adam + clamp, HIP-event kernel times, the
+algorithmic-bytes roofline of the survey with the matrix-pipe figures beside it).  The driver runs the default workload only; these
+records are kept under profiles/.
+
+    lut33    config 3: a 33^3 colour LUT (RGB -> RGB) as one crop, 3D method 3 (the reference's permuted trilinear weights), grids
+             ceil(33/4)+1 = 10 and 6 nodes per axis; N = 35 937 per step (launch-latency regime)
+    vol64    the 64^3 volume the reference's own sweeps use (method 3 and 4)
+    vol128   a 128^3 volume, method 3 and 4
+    video    config 4, one rank's slab of the 1920 x 1080 x 64 video field (x <-> T, y <-> H, z <-> W; grids [12,481,271,17] +
+             [12,241,136,9] at full size): z in [240 r, 240 r + 240), 16.6 Mvox per step, method 4 (and 3)
+    default  the reference's default step: IMAGE_SIZE 512, 8 random crops of 256 x 256, through the product's host loop
+    fits8    config 5, one GPU's share: 8 independent 1080p fits, each with its own grids / decoder / optimiser state and stream -
+             concurrently with an eighth of the CUs each (nic_path_desc.max_workgroups) against the same 8 steps back to back
+"""
+import json
+import math
+import time
+
+import numpy as np
+import torch
+
+PEAK_HBM_GBS = 8000.0
+PEAK_FP32_MATRIX_TFLOPS = 157.3
+
+
+def _work(dim, method):
+    k0 = 4 if (dim == 2 or method == 4) else 8
+    k1 = 4 if dim == 2 else 8
+    cin = 12 * (k0 + 1) + 6 * dim + 1
+    flop = 6 * (cin * 64 + 64 * 64 + 3 * 64)
+    byt = (k0 + k1) * 12 * 4 + 2 * (k0 + k1) * 12 * 4 + 3 * 4          # fp32 parameters / gradients / targets (SURVEY 8d formula)
+    return cin, flop, byt
+
+
+def _pct(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    return {"n": int(xs.size), "median": round(float(np.median(xs)), 4), "p10": round(float(np.percentile(xs, 10)), 4),
+            "p90": round(float(np.percentile(xs, 90)), 4), "min": round(float(xs.min()), 4)}
+
+
+def _fit_state(dev, dim, method, grid_base, seed=0, shapes=None):
+    from neural_image_compression_v2_amd import fp_def
+    from neural_image_compression_v2_amd.image_compression import ColorDecoder
+    torch.manual_seed(seed)
+    cin, _, _ = _work(dim, method)
+    if shapes is not None:                                   # explicit node counts (sizes that are not multiples of 8 samples)
+        fp = [torch.rand(*sh, device=dev) - 0.498 for sh in shapes]
+    else:
+        mk = fp_def.create_pyramid if dim == 2 else fp_def.create_pyramid_3d
+        fp, _ = mk(grid_base, 12, 8, dev, torch.float32, True)
+    dec = ColorDecoder(cin, 64).to(dev)
+    params = [p.detach() for p in dec.linear_params()]
+    tensors = params + [fp[0].detach(), fp[1].detach()]
+    return {"g0": fp[0].detach(), "g1": fp[1].detach(), "params": params, "tensors": tensors,
+            "m": [torch.zeros_like(t) for t in tensors], "v": [torch.zeros_like(t) for t in tensors], "flat": None}
+
+
+def _adam(lib, _lib, st, out, i, total, stream):
+    lrs = [0.005] * 6 + [0.01, 0.01]
+    q_lo = -(2 ** 8 - 1) / 2 ** 9
+    cos = 0.5 * (1 + math.cos(math.pi * i / max(total, 1)))
+    grads = out.grad_mlp + [out.grad_g0, out.grad_g1]
+    tab = (_lib.NicAdamTensor * 8)()
+    for k, (p, g, m, v) in enumerate(zip(st["tensors"], grads, st["m"], st["v"])):
+        lo, hi = (q_lo, 0.5) if k >= 6 else (1.0, -1.0)
+        tab[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), i + 1, lrs[k] * cos, lo, hi)
+    _lib.check(lib.nic_adam_multi(tab, 8, 0.9, 0.999, 1e-8, stream), "nic_adam_multi")
+
+
+def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=True, shapes=None):
+    """one crop = the whole volume (or slab) per step"""
+    from neural_image_compression_v2_amd import _lib, fused
+    lib = _lib.load()
+    st = _fit_state(dev, dim, method, grid_base, shapes=shapes)
+    n = int(np.prod(extent))
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    target = torch.rand(n, 3, generator=g).to(dev)
+    org = [list(origin)]
+    total = args.warmup + args.steps
+    stream = _lib.stream_ptr(dev)
+    flat = None
+
+    def step(i, ev=None):
+        nonlocal flat
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=tuple(extent), num_crops=1,
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, split_bf16=split)
+        out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], target, flat=flat, events=ev)
+        flat = out.flat
+        _adam(lib, _lib, st, out, i, total, stream)
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i, ev[i])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    kms = [a.elapsed_time(b) for a, b in ev]
+    cin, flop, byt = _work(dim, method)
+    km = float(np.median(kms))
+    unit = "Mvoxels/s" if dim == 3 else "Mpixels/s"
+    gbs = byt * n / (km * 1e-3) / 1e9
+    tfl = flop * n / (km * 1e-3) / 1e12
+    return {"metric": f"{unit[:-2]}/sec train-step (fwd+bwd + Adam + clamp), {name}", "value": round(n / dt / 1e6, 2), "unit": unit, "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": ("bf16x2-split chained products, f32 weight-gradient products, f32 accumulate" if (split and dim == 3)
+                                           else ("bf16x2-split operands, f32 accumulate" if split else "f32")),
+            "data": "synthetic",
+            "config": {"workload": name, "samples_per_step": n, "extent": list(extent), "grids": [list(st["g0"].shape), list(st["g1"].shape)],
+                       "method": method, "cin": cin, "final_loss": round(float(out.loss), 6)},
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "traffic": None, "kernel_ms": round(km, 4), "stats": _pct(kms), "bytes_per_sample": byt, "flop_per_sample": flop,
+                         "samples_per_launch": n,
+                         "mfma_f32_equivalent": {"achieved": round(tfl, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": round(tfl / PEAK_FP32_MATRIX_TFLOPS, 4)}}}
+
+
+def _run_default(args, dev):
+    """the reference's default step shape through the product's host loop (origins from the reference's RNG calls)"""
+    import random
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True)
+    S = cfg.IMAGE_SIZE
+    u = torch.linspace(0, 1, S)
+    img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :] for c in range(3)])
+    ic = ImageCompression(cfg, dev, seed=0)
+    ic.set_images([torch.round(img.clamp(0, 1) * 255).to(torch.uint8)])
+    torch.manual_seed(1)
+    random.seed(1)
+    for e in range(args.warmup):
+        ic.train_step(ic.feature_pyramid, e)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(args.warmup, args.warmup + args.steps):
+        ic.train_step(ic.feature_pyramid, e)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    px = cfg.NUM_CROPS * 256 * 256
+    cin, flop, byt = _work(2, 1)
+    return {"metric": "Mpixels/sec train-step, the reference's default 8 x 256^2 random-crop step (host loop included)", "value": round(px / dt / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2-split operands, f32 accumulate", "data": "synthetic",
+            "config": {"workload": "IMAGE_SIZE 512, 8 random crops of 256 x 256 per step (var2.py defaults), targets from the resident uint8 image, "
+                                   "one-launch Adam", "samples_per_step": px, "psnr_db": round(float(ic.psnr(ic.feature_pyramid)), 3)},
+            "roofline": {"bound": "hbm", "achieved": round(byt * px / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(byt * px / dt / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "note": "whole step (host loop) over the algorithmic bytes"}}
+
+
+def _run_fits8(args, dev):
+    """config 5 on one GPU: 8 independent 1080p fits; concurrent on 8 streams (an eighth of the CUs each) vs back to back (whole chip each)"""
+    from neural_image_compression_v2_amd import _lib, fused
+    lib = _lib.load()
+    HH, WW, NF = 1080, 1920, 8
+    fits, targets, streams = [], [], []
+    g = torch.Generator(device="cpu").manual_seed(99)
+    for k in range(NF):
+        fits.append(_fit_state(dev, 2, 1, (HH // 4, WW // 4), seed=k))
+        targets.append(torch.rand(HH * WW, 3, generator=g).to(dev))
+        streams.append(torch.cuda.Stream(dev))
+    org = [[0, 0]]
+    total = args.warmup + args.steps
+    cu = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def one(k, i, max_wg):
+        st = fits[k]
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(HH, WW), num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL,
+                                 noise_seed=7 + k, noise_offset=i, split_bf16=True, max_workgroups=max_wg)
+        out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], targets[k], flat=st["flat"])
+        st["flat"] = out.flat
+        _adam(lib, _lib, st, out, i, total, _lib.stream_ptr(dev))
+        return out
+
+    res = {}
+    for mode in ("back_to_back", "concurrent"):
+        def sweep(i):
+            outs = []
+            for k in range(NF):
+                if mode == "concurrent":
+                    with torch.cuda.stream(streams[k]):
+                        outs.append(one(k, i, cu // NF))
+                else:
+                    outs.append(one(k, i, 0))
+            return outs
+        for i in range(args.warmup):
+            sweep(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            outs = sweep(args.warmup + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        res[mode] = {"ms_per_sweep": round(dt * 1e3, 4), "mpix_s": round(NF * HH * WW / dt / 1e6, 2), "loss_fit0": round(float(outs[0].loss), 6)}
+    best = max(res, key=lambda m: res[m]["mpix_s"])
+    cin, flop, byt = _work(2, 1)
+    return {"metric": "aggregate Mpixels/sec, 8 independent 1080p fits on one MI355X (BASELINE config 5, one GPU's share)", "value": res[best]["mpix_s"],
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res[best]["ms_per_sweep"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2-split operands, f32 accumulate", "data": "synthetic",
+            "config": {"workload": "8 x (1920 x 1080 fit, own grids [12,481,271] + [12,241,136], own decoder, own Adam state), one step of each per sweep",
+                       "modes": res, "reported": best, "cus_per_fit_when_concurrent": cu // NF},
+            "roofline": {"bound": "hbm", "achieved": round(byt * res[best]["mpix_s"] * 1e6 / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(byt * res[best]["mpix_s"] * 1e6 / 1e9 / PEAK_HBM_GBS, 4), "traffic": None}}
+
+
+def run(args):
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w = args.workload
+    recs = []
+    if w == "lut33":
+        recs.append(_run_volume(args, dev, "33^3 colour LUT, one crop, method 3 (reference weights), grids 10^3 + 6^3", 3, 3, (33, 33, 33), None, (0, 0, 0),
+                                shapes=[(12, 10, 10, 10), (12, 6, 6, 6)]))
+    elif w in ("vol64", "vol128"):
+        S = 64 if w == "vol64" else 128
+        for method in (3, 4):
+            recs.append(_run_volume(args, dev, f"{S}^3 volume, one crop, method {method}", 3, method, (S, S, S), S // 4, (0, 0, 0)))
+    elif w == "video":
+        for method in (4, 3):
+            recs.append(_run_volume(args, dev, f"1920x1080x64 video field, rank 3's slab z in [720, 960) of 8, method {method}", 3, method, (64, 1080, 240),
+                                    (16, 270, 480), (0, 0, 720)))
+    elif w == "default":
+        recs.append(_run_default(args, dev))
+    elif w == "fits8":
+        recs.append(_run_fits8(args, dev))
+    else:
+        raise SystemExit(f"unknown workload {w}")
+    for r in recs:
+        print(json.dumps(r), flush=True)

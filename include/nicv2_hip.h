@@ -87,7 +87,10 @@ typedef struct nic_path_desc {
                               * dy rows (N = num_crops * passes * n_per_crop) - the same result as listing the crop `passes` times, but
                               * a cell's gradients are summed over all passes before they go to memory (stripe-sharded multi-GPU steps).
                               * Every other entry point: 0 or 1. */
-    int32_t reserved0;       /* 0 */
+    int32_t max_workgroups;  /* 0: the launch may fill the chip (one persistent workgroup per CU, two for inference).  n > 0: at most n
+                              * workgroups (rounded down to a multiple of 8, at least 8): independent fits launched on separate
+                              * streams (BASELINE config 5) then share the CUs side by side instead of queueing behind each other's
+                              * persistent grids. */
 } nic_path_desc;
 /* Every crop origin is a multiple of the cell size 1 / step_number (1 when step_number >= 1), e.g. whole-image passes from
  * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1

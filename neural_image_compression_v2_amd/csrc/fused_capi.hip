@@ -70,6 +70,7 @@ int reduce(int layout, const float* partials, int n_waves, nic_mlp_grads g, floa
 
 int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->num_crops < 1) return NIC_E_SHAPE;
+    if (d->max_workgroups < 0) return NIC_E_ARG;
     if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
@@ -94,7 +95,7 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 #define NIC_RG_MAX 2
 #endif
 void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
-    const int64_t waves = (int64_t)(cu_count() * per_cu / 8 * 8) * waves_per_wg;
+    const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
     double best = 0.0;
@@ -105,10 +106,19 @@ void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
     }
 }
 
-int grid_for(int64_t n_tiles, int per_cu, int waves_per_wg = 4) {
+// workgroups a launch may use: one (two: inference) per CU, or nic_path_desc.max_workgroups when the caller shares the chip
+int64_t wg_cap(int per_cu, int max_wg) {
+    int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
+    if (max_wg > 0) {
+        const int64_t lim = max_wg / 8 * 8 < 8 ? 8 : max_wg / 8 * 8;
+        if (lim < cap) cap = lim;
+    }
+    return cap;
+}
+int grid_for(int64_t n_tiles, int per_cu, int waves_per_wg = 4, int max_wg = 0) {
     int64_t want = (n_tiles + waves_per_wg - 1) / waves_per_wg;                 // one tile per wave
     want = (want + 7) / 8 * 8;
-    const int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
+    const int64_t cap = wg_cap(per_cu, max_wg);
     if (want > cap) want = cap;
     if (want < 8) want = 8;
     return (int)want;
@@ -219,7 +229,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
     balance_units(p, 1, wpw);
     if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;     // the kernels count work units in 32 bits
-    const int grid = grid_for(p.n_tiles << p.rg_log2, 1, wpw);
+    const int grid = grid_for(p.n_tiles << p.rg_log2, 1, wpw, d->max_workgroups);
     const int n_rec = grid;                                   // one record per workgroup
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -264,7 +274,7 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     fill_mlp(p, mlp);
     p.y = y;
     balance_units(p, 2);
-    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2), (hipStream_t)stream);
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);
 }
 
 int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uint8_t* g1_u8, const int32_t* origins, const nic_mlp* mlp,
@@ -286,7 +296,7 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     p.dq_rcp = 1.0f / p.dq_den;
     p.y = y; p.y_u8 = y_u8;
     balance_units(p, 2);
-    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2), (hipStream_t)stream);
+    return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);
 }
 
 int nic_fused_forward_backward(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,

@@ -82,6 +82,7 @@ class PathGeometry:
     split_bf16: bool = False             # 2D training steps: matrix products as hi + lo bf16 pairs on the bf16 pipe (NIC_FLAG_SPLIT_BF16)
     passes: int = 1                      # training steps: every crop sampled `passes` times in one launch (nic_path_desc.passes)
     split_tile32: bool = False           # with split_bf16, 2D training: the 4-wave x 32-sample kernel instead of the 8-wave x 16-sample default
+    max_workgroups: int = 0              # > 0: the launch takes at most this many workgroups (concurrent fits on separate streams share the CUs)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -138,6 +139,7 @@ class PathGeometry:
         d.loss_scale = float(self.loss_scale) if self.loss_scale is not None else 1.0 / (3.0 * self.n_samples)
         d.flags = int(self.flags) | (_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0)
         d.passes = int(self.passes)
+        d.max_workgroups = int(self.max_workgroups)
         if self.split_bf16 or os.environ.get("NIC_FORCE_SPLIT_BF16") == "1":   # env: test switch for the whole suite
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         if self.split_tile32:
