@@ -168,7 +168,7 @@ def main():
                          "within 5e-6 of the fp32 kernel; the product's default for 2D training); f32: v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
                     help="tensor: resident fp32 [N,3] targets (the reference's crop stack, built once); image: targets read from the "
-                         "resident uint8 image inside the step (a quarter of the bytes, ~3 %% more kernel time: three byte gathers)")
+                         "resident RGBX uint8 image inside the step (a third of the bytes, one dword load per sample)")
     ap.add_argument("--shard", choices=["stripes", "replicated"], default="stripes",
                     help="N > 1.  stripes: every rank owns a stripe of the image's second axis (a contiguous block of grid node rows) and "
                          "takes its N passes per step from it; the step exchanges the loss, the decoder gradients and one boundary node "
@@ -227,8 +227,9 @@ def main():
     params = [p.detach() for p in dec.linear_params()]
     g0, g1 = fp[0].detach(), fp[1].detach()
     target, img = synthetic_target(dev)
-    if args.target == "image":                                        # 8-bit codes of the same image, resident: u / 255 = img exactly
-        target = fused.TargetImage(torch.round(img * 255).to(torch.uint8).to(dev), 255.0)
+    if args.target == "image":                                        # 8-bit codes of the same image, resident and RGBX-interleaved: u / 255 = img exactly
+        from neural_image_compression_v2_amd.sampler import rgbx_interleave
+        target = fused.TargetImage(rgbx_interleave(torch.round(img * 255).to(torch.uint8).to(dev)), 255.0, rgbx=True)
     n_local = H * W
     vworld = args.virtual_world if world == 1 and args.virtual_world > 1 else world
     n_global = n_local * vworld

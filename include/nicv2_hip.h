@@ -184,7 +184,9 @@ int nic_fused_forward(const nic_path_desc *desc, const float *g0, const float *g
  *      ToTensor, image_compression.py:436-440; den 256: the 3D loader, :474).  Every origin + extent must lie inside `size`. */
 typedef struct nic_target_image {
     const void *data;
-    int32_t is_u8;
+    int32_t is_u8;       /* 0: fp32 planar [3, S0, S1(, S2)].  1: uint8 planar, target = u / den.  2: uint8 RGBX interleaved
+                          *    [S0, S1(, S2)] dwords R | G << 8 | B << 16 (nic_rgbx_interleave / nic_rgbx_downsample2): the three
+                          *    targets of a sample are ONE load, target = byte / den */
     float den;           /* uint8 only */
     int32_t size[3];     /* S0, S1, S2 (1 for 2D) */
     int32_t reserved;
@@ -193,6 +195,24 @@ int nic_fused_forward_backward_img(const nic_path_desc *desc, const float *g0, c
                                    const nic_mlp *mlp, const float *noise, const nic_target_image *image, float *y, float *loss,
                                    float *g0_grad, float *g1_grad, const nic_mlp_grads *grads, void *workspace,
                                    size_t workspace_bytes, void *stream);
+
+/* ---- device-side sampler (image_compression.py:26-50, 221-226).  The reference draws the LOD with Python's
+ *      `random` and the crop origins with torch.randint on the host and uploads them every step; this counter-based generator
+ *      (Threefry-4x32-12 keyed by seed, step and crop; csrc/nic_device.hpp::sampler_block) gives the same LAWS - LOD uniform on
+ *      0..max_mip, or floor(-log2 U / 2) = clz(word) >> 1; origins uniform on [0, range) per axis - without host RNG state:
+ *      the LOD decides the launch geometry, so it is evaluated on the host (pure function, no GPU); the origins are written by a
+ *      tiny kernel straight into the int32 [num_crops, dim] device buffer the fused entry points read - no upload per step.
+ *      nic_sampler_origins_host is the same function on the host (tests, debugging). */
+int nic_sampler_lod_host(uint64_t seed, uint64_t step, int uniform_distribution, int max_mip_level);
+int nic_sampler_origins_host(uint64_t seed, uint64_t step, int num_crops, int dim, int32_t range, int32_t *origins_host);
+int nic_sampler_draw_origins(uint64_t seed, uint64_t step, int num_crops, int dim, int32_t range, int32_t *origins, void *stream);
+
+/* ---- resident RGBX target images: planar uint8 [3][n] (the codes ToTensor / the 3D loader divide, image_compression.py:436-440, 474)
+ *      -> n dwords; and the next level of a 2D mip chain by a 2 x 2 box filter with round-to-nearest (the reference resizes with
+ *      torchvision's Resize, :429-477: its filter is not reproduced - targets at mip > 0 are this library's own definition;
+ *      mip 0, the only level of the no-mip default, is exact). */
+int nic_rgbx_interleave(const uint8_t *planar, int64_t n, uint32_t *rgbx, void *stream);
+int nic_rgbx_downsample2(const uint32_t *src_rgbx, int s0, int s1, uint32_t *dst_rgbx, void *stream);
 
 /* ---- decode straight from the stored codec (image_compression.py:307-346 after fp_load, fp_def.py:258-263):
  *      the grids are the uint8 tensors fp_savable wrote (models.py:61-64), dequantised in-kernel exactly like load4fp

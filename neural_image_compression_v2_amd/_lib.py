@@ -94,6 +94,11 @@ SIGNATURES = {
     "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _DBL, _DBL, _DBL, _DBL, _L, _F, _F, _P]),
     "nic_gather_corners": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P]),
     "nic_adam_multi": (_I, [ctypes.POINTER(NicAdamTensor), _I, _DBL, _DBL, _DBL, _P]),
+    "nic_sampler_lod_host": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I]),
+    "nic_sampler_origins_host": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    "nic_sampler_draw_origins": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, _P, _P]),
+    "nic_rgbx_interleave": (_I, [_P, _L, _P, _P]),
+    "nic_rgbx_downsample2": (_I, [_P, _I, _I, _P, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

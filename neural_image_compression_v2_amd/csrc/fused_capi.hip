@@ -94,6 +94,15 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 #ifndef NIC_RG_MAX
 #define NIC_RG_MAX 2
 #endif
+// workgroups a launch may use: one (two: inference) per CU, or nic_path_desc.max_workgroups when the caller shares the chip
+int64_t wg_cap(int per_cu, int max_wg) {
+    int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
+    if (max_wg > 0) {
+        const int64_t lim = max_wg / 8 * 8 < 8 ? 8 : max_wg / 8 * 8;
+        if (lim < cap) cap = lim;
+    }
+    return cap;
+}
 void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
     const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
@@ -106,15 +115,6 @@ void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
     }
 }
 
-// workgroups a launch may use: one (two: inference) per CU, or nic_path_desc.max_workgroups when the caller shares the chip
-int64_t wg_cap(int per_cu, int max_wg) {
-    int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
-    if (max_wg > 0) {
-        const int64_t lim = max_wg / 8 * 8 < 8 ? 8 : max_wg / 8 * 8;
-        if (lim < cap) cap = lim;
-    }
-    return cap;
-}
 int grid_for(int64_t n_tiles, int per_cu, int waves_per_wg = 4, int max_wg = 0) {
     int64_t want = (n_tiles + waves_per_wg - 1) / waves_per_wg;                 // one tile per wave
     want = (want + 7) / 8 * 8;
@@ -221,7 +221,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_s[1] = s2;
         p.timg_s[0] = (int64_t)img->size[1] * s2;
         p.timg_cs = (int64_t)img->size[0] * p.timg_s[0];
-        p.timg_u8 = img->is_u8 ? 1 : 0;
+        if (img->is_u8 < 0 || img->is_u8 > 2) return NIC_E_ARG;
+        p.timg_u8 = img->is_u8;
         p.timg_den = img->is_u8 ? img->den : 1.0f;
         p.timg_rcp = 1.0f / p.timg_den;
     }

@@ -981,10 +981,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         if (MODE == MODE_TRAIN_IMG) {
             int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
             if (L::DIM == 3) off += (int64_t)q[2] * p.timg_s[2];
+            uint32_t rgbx = 0u;
+            if (p.timg_u8 == 2) rgbx = reinterpret_cast<const uint32_t*>(p.timg)[off];      // interleaved: one load for the three targets
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (p.timg_u8) {
-                    const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                    const float u = p.timg_u8 == 2 ? (float)((rgbx >> (8 * c)) & 255u) : (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
                     const float t0 = mul_rn(u, p.timg_rcp);                               // correctly rounded u / den, as in grid_elem
                     tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
                 } else {

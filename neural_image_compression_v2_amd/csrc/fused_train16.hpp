@@ -449,10 +449,12 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 float tgt[3] = {0.f, 0.f, 0.f};
                 if (MODE == MODE_TRAIN_IMG) {
                     const int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
+                    uint32_t rgbx = 0u;
+                    if (p.timg_u8 == 2) rgbx = reinterpret_cast<const uint32_t*>(p.timg)[off];      // interleaved: one load for the three targets
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if (p.timg_u8) {
-                            const float u = (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                            const float u = p.timg_u8 == 2 ? (float)((rgbx >> (8 * c)) & 255u) : (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
                             const float t0 = mul_rn(u, p.timg_rcp);
                             tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
                         } else {

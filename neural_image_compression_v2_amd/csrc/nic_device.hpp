@@ -176,18 +176,19 @@ __device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rc
 struct U4 {
     uint32_t x, y, z, w;
 };
-__device__ __forceinline__ U4 threefry4x32_12(U4 c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ U4 threefry4x32_12(U4 c, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     const uint32_t ks[5] = {k0, k1, k2, k3, 0x1BD11BDAu ^ k0 ^ k1 ^ k2 ^ k3};
     uint32_t x0 = c.x + ks[0], x1 = c.y + ks[1], x2 = c.z + ks[2], x3 = c.w + ks[3];
     constexpr int R[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
         if ((r & 1) == 0) {
-            x0 += x1; x1 = __builtin_rotateleft32(x1, R[r & 7][0]) ^ x0;
-            x2 += x3; x3 = __builtin_rotateleft32(x3, R[r & 7][1]) ^ x2;
+            x0 += x1; x1 = rotl32(x1, R[r & 7][0]) ^ x0;
+            x2 += x3; x3 = rotl32(x3, R[r & 7][1]) ^ x2;
         } else {
-            x0 += x3; x3 = __builtin_rotateleft32(x3, R[r & 7][0]) ^ x0;
-            x2 += x1; x1 = __builtin_rotateleft32(x1, R[r & 7][1]) ^ x2;
+            x0 += x3; x3 = rotl32(x3, R[r & 7][0]) ^ x0;
+            x2 += x1; x1 = rotl32(x1, R[r & 7][1]) ^ x2;
         }
         if (((r + 1) & 3) == 0) {
             const int q = (r + 1) >> 2;
@@ -195,6 +196,35 @@ __device__ __forceinline__ U4 threefry4x32_12(U4 c, uint32_t k0, uint32_t k1, ui
         }
     }
     return U4{x0, x1, x2, x3};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Counter-based sampler (replaces the host RNG calls of random_crop_dataset, image_compression.py:26-50, when the
+// caller opts in).  One generator block per (seed, step, crop): block = threefry4x32_12(ctr = (step_lo, step_hi, crop, "SAMP"),
+// key = (seed_lo, seed_hi, "NIC2", 1)).  Crop origin along axis a = (word_a * range) >> 32 (multiply-shift: uniform on [0, range)
+// up to range / 2^32).  The LOD of a step comes from the block of crop 0xFFFFFFFF: uniform = (word_1 * (max_mip + 1)) >> 32;
+// otherwise floor(-log2(U) / 2) with U = (word_0 + 1/2) / 2^32, which is exactly clz(word_0) >> 1 - the reference's
+// P(lod = k) = 3/4 * 4^-k (image_compression.py:32) in integer arithmetic, identical on host and device.
+// Restated in oracle/nic_oracle.py::sampler_block / sampler_lod / sampler_origins.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ U4 sampler_block(uint64_t seed, uint64_t step, uint32_t crop) {
+    const U4 c{(uint32_t)step, (uint32_t)(step >> 32), crop, 0x53414D50u /* "SAMP" */};
+    return threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32), 0x4E494332u /* "NIC2" */, 1u);
+}
+__host__ __device__ __forceinline__ int sampler_origin(const U4& b, int axis, uint32_t range) {
+    const uint32_t w = axis == 0 ? b.x : (axis == 1 ? b.y : b.z);
+    return (int)(((uint64_t)w * (uint64_t)range) >> 32);
+}
+__host__ __device__ __forceinline__ int clz32(uint32_t x) {
+    int n = 0;
+    if (x == 0) return 32;
+    while (!(x & 0x80000000u)) { x <<= 1; ++n; }
+    return n;
+}
+__host__ __device__ __forceinline__ int sampler_lod(uint64_t seed, uint64_t step, int uniform, int max_mip) {
+    const U4 b = sampler_block(seed, step, 0xFFFFFFFFu);
+    const int lod = uniform ? (int)(((uint64_t)b.y * (uint64_t)(max_mip + 1)) >> 32) : (clz32(b.x) >> 1);
+    return lod > max_mip ? max_mip : lod;
 }
 
 struct NoiseSrc {

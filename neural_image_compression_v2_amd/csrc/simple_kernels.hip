@@ -328,6 +328,37 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Device-side sampler and resident RGBX targets
+// ---------------------------------------------------------------------------------------------------
+__global__ void draw_origins_kernel(uint64_t seed, uint64_t step, int num_crops, int dim, uint32_t range, int32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_crops) return;
+    const nic::U4 b = nic::sampler_block(seed, step, (uint32_t)i);
+    for (int a = 0; a < dim; ++a) out[i * dim + a] = nic::sampler_origin(b, a, range);
+}
+// planar uint8 [3][n] -> interleaved R | G << 8 | B << 16 (one dword per sample: the fused kernels fetch a target with ONE load)
+__global__ void __launch_bounds__(256) rgbx_interleave_kernel(const uint8_t* src, int64_t n, uint32_t* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (uint32_t)src[i] | ((uint32_t)src[n + i] << 8) | ((uint32_t)src[2 * n + i] << 16);
+}
+// 2 x 2 box filter, round to nearest (ties up): [s0][s1] RGBX -> [s0/2][s1/2] RGBX
+__global__ void __launch_bounds__(256) rgbx_down2_kernel(const uint32_t* src, int s0, int s1, uint32_t* dst) {
+    const int d0 = s0 >> 1, d1 = s1 >> 1;
+    const int64_t n = (int64_t)d0 * d1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i / d1), y = (int)(i - (int64_t)x * d1);
+        const uint32_t a = src[(int64_t)(2 * x) * s1 + 2 * y], b = src[(int64_t)(2 * x) * s1 + 2 * y + 1];
+        const uint32_t c = src[(int64_t)(2 * x + 1) * s1 + 2 * y], d = src[(int64_t)(2 * x + 1) * s1 + 2 * y + 1];
+        uint32_t o = 0;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t sum = ((a >> (8 * k)) & 255u) + ((b >> (8 * k)) & 255u) + ((c >> (8 * k)) & 255u) + ((d >> (8 * k)) & 255u);
+            o |= ((sum + 2u) >> 2) << (8 * k);
+        }
+        dst[i] = o;
+    }
+}
+
 static inline int blocks_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -510,6 +541,39 @@ int nic_psnr(const float* a, const float* b, int64_t n, int num_bits, float* out
     if (nb > kPsnrBlocks) nb = kPsnrBlocks;
     hipLaunchKernelGGL(sqerr_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, n, (double*)workspace);
     hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, n, (float)(1 << num_bits), out2);
+    return (int)hipGetLastError();
+}
+
+int nic_sampler_lod_host(uint64_t seed, uint64_t step, int uniform, int max_mip) {
+    if (max_mip < 0) return NIC_E_ARG;
+    return nic::sampler_lod(seed, step, uniform, max_mip);
+}
+int nic_sampler_origins_host(uint64_t seed, uint64_t step, int num_crops, int dim, int32_t range, int32_t* origins_host) {
+    if (!origins_host) return NIC_E_NULL;
+    if (num_crops < 0 || dim < 1 || dim > 3 || range < 1) return NIC_E_ARG;
+    for (int i = 0; i < num_crops; ++i) {
+        const nic::U4 b = nic::sampler_block(seed, step, (uint32_t)i);
+        for (int a = 0; a < dim; ++a) origins_host[i * dim + a] = nic::sampler_origin(b, a, (uint32_t)range);
+    }
+    return NIC_OK;
+}
+int nic_sampler_draw_origins(uint64_t seed, uint64_t step, int num_crops, int dim, int32_t range, int32_t* origins, void* stream) {
+    if (!origins) return NIC_E_NULL;
+    if (num_crops < 1 || dim < 1 || dim > 3 || range < 1) return NIC_E_ARG;
+    hipLaunchKernelGGL(draw_origins_kernel, dim3((num_crops + 63) / 64), dim3(64), 0, (hipStream_t)stream, seed, step, num_crops, dim, (uint32_t)range, origins);
+    return (int)hipGetLastError();
+}
+int nic_rgbx_interleave(const uint8_t* planar, int64_t n, uint32_t* rgbx, void* stream) {
+    if (!planar || !rgbx) return NIC_E_NULL;
+    if (n < 0) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    hipLaunchKernelGGL(rgbx_interleave_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, planar, n, rgbx);
+    return (int)hipGetLastError();
+}
+int nic_rgbx_downsample2(const uint32_t* src, int s0, int s1, uint32_t* dst, void* stream) {
+    if (!src || !dst) return NIC_E_NULL;
+    if (s0 < 2 || s1 < 2) return NIC_E_ARG;
+    hipLaunchKernelGGL(rgbx_down2_kernel, dim3(blocks_for((int64_t)(s0 >> 1) * (s1 >> 1))), dim3(256), 0, (hipStream_t)stream, src, s0, s1, dst);
     return (int)hipGetLastError();
 }
 

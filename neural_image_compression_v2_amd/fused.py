@@ -309,30 +309,41 @@ class TargetImage:
     (image_compression.py:37-47) is never built.  ``image``: the dataset tensor ``[3, S0, S1(, S2)]`` on the device, fp32, or
     uint8 codes with ``den`` (255: ToTensor, :436-440; 256: the 3D loader, :474; value = u / den, correctly rounded)."""
 
-    def __init__(self, image: torch.Tensor, den: float = 255.0):
-        if not isinstance(image, torch.Tensor) or image.dim() not in (3, 4) or image.shape[0] != 3:
+    def __init__(self, image: torch.Tensor, den: float = 255.0, rgbx: bool = False):
+        """``rgbx``: ``image`` is the interleaved form ``[S0, S1(, S2)]`` int32 (R | G << 8 | B << 16 per sample, :func:`rgbx_interleave`):
+        the kernel fetches a sample's three targets with one load."""
+        self.rgbx = bool(rgbx)
+        if self.rgbx:
+            if not isinstance(image, torch.Tensor) or image.dtype != torch.int32 or image.dim() not in (2, 3):
+                raise ValueError("an RGBX image is an int32 tensor [S0, S1] or [S0, S1, S2]")
+        elif not isinstance(image, torch.Tensor) or image.dim() not in (3, 4) or image.shape[0] != 3:
             raise ValueError("image must be [3, S0, S1] or [3, S0, S1, S2]")
         if not image.is_cuda:
             raise RuntimeError(f"image lives on {image.device}: this package only runs on a HIP device (no CPU path)")
-        if image.dtype not in (torch.float32, torch.uint8):
+        if not self.rgbx and image.dtype not in (torch.float32, torch.uint8):
             raise NotImplementedError("resident images are fp32 or uint8")
         self.image = image.contiguous()
         self.den = float(den)
 
+    @property
+    def spatial(self):
+        return tuple(self.image.shape) if self.rgbx else tuple(self.image.shape[1:])
+
     def to_struct(self, geo: "PathGeometry", coord) -> _lib.NicTargetImage:
-        if self.image.dim() != geo.dim + 1:
+        sp = self.spatial
+        if len(sp) != geo.dim:
             raise ValueError("image / geometry dimension mismatch")
         if not (isinstance(coord, torch.Tensor) and coord.is_cuda):     # device origins are taken as is (no sync), like upload_origins
             o = torch.as_tensor(coord).reshape(-1, geo.dim).to(torch.int64)
             for a in range(geo.dim):
-                if int(o[:, a].min()) < 0 or int(o[:, a].max()) + int(geo.extent[a]) > int(self.image.shape[1 + a]):
-                    raise IndexError(f"axis {a}: crop leaves the image ({int(o[:, a].max())} + {geo.extent[a]} > {self.image.shape[1 + a]})")
+                if int(o[:, a].min()) < 0 or int(o[:, a].max()) + int(geo.extent[a]) > int(sp[a]):
+                    raise IndexError(f"axis {a}: crop leaves the image ({int(o[:, a].max())} + {geo.extent[a]} > {sp[a]})")
         t = _lib.NicTargetImage()
         t.data = self.image.data_ptr()
-        t.is_u8 = 1 if self.image.dtype == torch.uint8 else 0
+        t.is_u8 = 2 if self.rgbx else (1 if self.image.dtype == torch.uint8 else 0)
         t.den = self.den
         for a in range(3):
-            t.size[a] = int(self.image.shape[1 + a]) if a < geo.dim else 1
+            t.size[a] = int(sp[a]) if a < geo.dim else 1
         return t
 
 

@@ -160,6 +160,14 @@ class ImageCompression:
         or the uint8 codes they were made from (``ToTensor`` = u / 255; the 3D loader = u / 256) at a quarter of the memory"""
         self.images = [im.to(self.device) for im in images]
         self._targets = [fused.TargetImage(im, den) for im in self.images]
+        self._sampler = None
+        if self.cfg.TF_DEVICE_SAMPLER:
+            # device-side sampler (sampler.py): RGBX levels built once from the level-0 codes, origins drawn on the device
+            from .sampler import DeviceSampler, build_rgbx_pyramid
+            if self.images[0].dtype != torch.uint8:
+                raise ValueError("TF_DEVICE_SAMPLER needs the uint8 codes of the image (set_images([...uint8...]))")
+            self._targets = build_rgbx_pyramid(self.images[0], self.cfg.MAX_MIP_LEVEL + 1, den)
+            self._sampler = DeviceSampler(self.cfg.SAMPLER_SEED, self.device, self.cfg.NUM_CROPS)
 
     # ------------------------------------------------------------------ one training iteration
     def train_step(self, fp, epoch: int, fused_step: bool = True, noise_seed: int = 7):
@@ -167,7 +175,14 @@ class ImageCompression:
         c = self.cfg
         D = c.FP_DIMENSION
         resident = fused_step and len(getattr(self, "_targets", ())) == len(self.images) and len(self.images) > 0
-        if resident:
+        if fused_step and getattr(self, "_sampler", None) is not None:
+            # device-side sampler: LOD on the host (pure function of seed and step), origins written on the device, targets from the RGBX level
+            sizes = [t.spatial[0] for t in self._targets]
+            coord, lod = self._sampler.draw(epoch, self._uniform(), c.MAX_MIP_LEVEL, c.CROP_SIZE, sizes, c.NUM_CROPS, D)   # coord stays on the device
+            fl = self.feature_pyramid_mip_levels_dict[lod]
+            resident = fp[2 * fl].requires_grad
+            target = self._targets[lod] if resident else self._crops_rgbx(self._targets[lod], coord.cpu(), max(1, c.CROP_SIZE // pow(2, lod)))
+        elif resident:
             coord, lod = self.random_crop_origins(self.images, c.CROP_SIZE, c.NUM_CROPS, self._uniform(), dim=D)
             fl = self.feature_pyramid_mip_levels_dict[lod]
             resident = fp[2 * fl].requires_grad
@@ -219,6 +234,18 @@ class ImageCompression:
             return t
         lut = (torch.arange(256, dtype=torch.float32) / den).to(t.device)    # divided on the host: correctly rounded, like ToTensor
         return lut[t.long()]
+
+    def _crops_rgbx(self, timg, coord: torch.Tensor, re_crop: int) -> torch.Tensor:
+        """[num_crops * n, 3] fp32 targets cut out of an RGBX level (the unfused tail after the freeze, device-sampler mode)"""
+        w = timg.image
+        D = w.dim()
+        rows = []
+        for start in coord:
+            sl = tuple(slice(int(start[d]), int(start[d]) + re_crop) for d in range(D))
+            rows.append(w[sl].reshape(-1))
+        codes = torch.cat(rows)
+        lut = (torch.arange(256, dtype=torch.float32) / timg.den).to(w.device)
+        return torch.stack([lut[((codes >> (8 * ch)) & 255).long()] for ch in range(3)], dim=1)
 
     def _uniform(self) -> bool:
         self._acc = getattr(self, "_acc", 0.0) + self.cfg.UNIFORM_DISTRIBUTION_RATE                    # :221-226

@@ -983,6 +983,123 @@ def test_targets_from_the_resident_image(dev):
             fused.fused_forward_backward(geo, g0, g1, [[isz[0] - ext[0] + 1] + [0] * (dim - 1)] * len(orgs), params, fused.TargetImage(img_f))
 
 
+def test_device_sampler_and_rgbx_targets(dev):
+    """SURVEY 8f rank 3, device side: (a) origins drawn by the kernel == the library's host twin == the oracle's restatement;
+    (b) the RGBX levels: level 0 = the image's codes interleaved, level k + 1 = the oracle's 2 x 2 box filter of level k;
+    (c) a training step whose targets are read from the RGBX image (one dword per sample) == the step on the materialised crop
+    stack, in 2D (den 255) and 3D (den 256), both arithmetic modes, origins left on the device."""
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.image_compression import ColorDecoder
+    from neural_image_compression_v2_amd.sampler import DeviceSampler, build_rgbx_pyramid, rgbx_interleave
+    smp = DeviceSampler(1234567, dev)
+    for step in (0, 3, 2 ** 34 + 1):
+        org, lod = smp.draw(step, False, 3, 64, [256, 128, 64, 32], 8, 2)
+        assert org.is_cuda and org.dtype == torch.int32 and tuple(org.shape) == (8, 2)
+        assert lod == O.sampler_lod(1234567, step, False, 3)
+        rng = [256, 128, 64, 32][lod] - max(1, 64 >> lod) + 1
+        assert_exact(org, smp.origins_host(step, 8, 2, rng), "device origins vs host twin")
+        assert_exact(org, O.sampler_origins(1234567, step, 8, 2, rng), "device origins vs oracle")
+    gen = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 96, 160), generator=gen, dtype=torch.uint8)
+    pyr = build_rgbx_pyramid(img.to(dev), 4)
+    lvl = img.permute(1, 2, 0).numpy()
+    for k, t_ in enumerate(pyr):
+        w = t_.image.cpu().numpy().astype(np.uint32)
+        got = np.stack([(w >> (8 * c)) & 255 for c in range(3)], axis=-1).astype(np.uint8)
+        assert got.shape == lvl.shape and np.array_equal(got, lvl), f"RGBX level {k}"
+        assert ((w >> 24) == 0).all()
+        lvl = O.rgbx_down2(lvl)
+    cases = [(2, 1, 73, (12, 41, 25), (12, 21, 13), (96, 160), (32, 24), [[5, 64], [64, 0], [40, 136]], 255.0),
+             (3, 4, 79, (12, 9, 9, 9), (12, 5, 5, 5), (32, 32, 32), (8, 8, 8), [[0, 3, 24], [17, 9, 1]], 256.0)]
+    for dim, method, cin, s0, s1, isz, ext, orgs, den in cases:
+        g0 = (torch.rand(*s0, generator=gen) - 0.5).to(dev)
+        g1 = (torch.rand(*s1, generator=gen) - 0.5).to(dev)
+        torch.manual_seed(40 + dim)
+        dec = ColorDecoder(cin, 64).to(dev)
+        params = [p.detach() for p in dec.linear_params()]
+        img_u8 = torch.randint(0, 256, (3, *isz), generator=gen, dtype=torch.uint8).to(dev)
+        img_f = img_u8.to(torch.float32) / den
+        crops = []
+        for o in orgs:
+            sl = tuple(slice(o[a], o[a] + ext[a]) for a in range(dim))
+            crops.append(img_f[(slice(None), *sl)].reshape(3, -1).T)
+        target = torch.cat(crops)
+        rg = fused.TargetImage(rgbx_interleave(img_u8), den, rgbx=True)
+        org_dev = torch.tensor(orgs, dtype=torch.int32, device=dev)
+        for split in (False, True):
+            geo = fused.PathGeometry(dim, method, 0.25, 0, ext, len(orgs), noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=3, noise_offset=9, split_bf16=split)
+            ref = fused.fused_forward_backward(geo, g0, g1, orgs, params, target, want_y=True)
+            out = fused.fused_forward_backward(geo, g0, g1, org_dev, params, rg, want_y=True)
+            assert_exact(out.y, ref.y, "RGBX targets: y")
+            assert_rel(out.loss, ref.loss, 1e-6, "RGBX targets: loss")
+            for a, b in zip([out.grad_g0, out.grad_g1] + out.grad_mlp, [ref.grad_g0, ref.grad_g1] + ref.grad_mlp):
+                assert_rel(a, b, 2e-6, "RGBX targets: gradients")
+
+
+def test_training_with_the_device_sampler_matches_the_oracle_loop(dev):
+    """TF_DEVICE_SAMPLER: the product's loop with LOD / origins from the counter-based sampler and targets from the resident RGBX
+    mip pyramid against the oracle's loop fed the oracle's restatement of the same draws and the oracle's box-filter chain (mips on:
+    LODs 0..4 occur): loss trajectory and final PSNR (peak 256) agree; no host RNG is consumed."""
+    import random
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    cfg = Settings(IMAGE_SIZE=256, NUM_EPOCHS=30, NUM_CROPS=2, TF_NO_MIP=False, MAX_MIP_LEVEL=4, CROP_MIP_LEVEL=8, UNIFORM_DISTRIBUTION_RATE=0.34,
+                   TF_DEVICE_SAMPLER=True, SAMPLER_SEED=77)
+    S = cfg.IMAGE_SIZE
+    gen = torch.Generator().manual_seed(4)
+    u = torch.linspace(0, 1, S)
+    img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :]
+                       for c in range(3)]) + 0.05 * (torch.rand(3, S, S, generator=gen) * 2 - 1)
+    codes = torch.round(img.clamp(0, 1) * 255).to(torch.uint8)
+    ic = ImageCompression(cfg, dev, seed=0)
+    ic.set_images([codes])
+    fp_ref = [f.detach().cpu().clone() for f in ic.feature_pyramid]
+    mlp_ref = O.MLPParams.from_state_dict({k: v.detach().cpu() for k, v in ic.decoder.state_dict().items()})
+    for tns in fp_ref + mlp_ref.tensors():
+        tns.requires_grad_(True)
+    opt = torch.optim.Adam([{"params": fp_ref, "lr": 0.01}, {"params": mlp_ref.tensors(), "lr": 0.005}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cfg.NUM_EPOCHS, eta_min=0)
+    st_t, st_p = torch.get_rng_state(), random.getstate()
+    fp = ic.train_models(ic.feature_pyramid, fused_step=True)
+    assert torch.equal(torch.get_rng_state(), st_t) and random.getstate() == st_p, "the device sampler must not touch the host RNGs"
+    losses_gpu = torch.stack(ic.loss_history).cpu().numpy()
+    # the oracle's datasets: level k + 1 = box filter of level k, value = code / 255
+    lv = [codes.permute(1, 2, 0).numpy()]
+    for _ in range(cfg.MAX_MIP_LEVEL):
+        lv.append(O.rgbx_down2(lv[-1]))
+    data = [torch.from_numpy(a.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).contiguous() for a in lv]
+    mp = O.create_pyramid_mip_levels(S, S // 4)
+    cur, frozen, acc, losses_ref, lods = fp_ref, False, 0.0, [], []
+    for epoch in range(cfg.NUM_EPOCHS):
+        acc += cfg.UNIFORM_DISTRIBUTION_RATE
+        uniform = acc >= 1.0
+        if uniform:
+            acc -= 1.0
+        if epoch > cfg.NUM_EPOCHS * 0.95 and not frozen:
+            for g_ in cur:
+                g_.requires_grad = False
+            cur = O.fp_all_quantize(cur, 8)
+            frozen = True
+        if frozen:
+            break                                                     # the frozen tail draws from the host RNG like the reference (unfused path)
+        lod = O.sampler_lod(77, epoch, uniform, cfg.MAX_MIP_LEVEL)
+        lods.append(lod)
+        re_crop = max(1, 256 >> lod)
+        coord = O.sampler_origins(77, epoch, 2, 2, data[lod].shape[1] - re_crop + 1)
+        fl = mp[lod]
+        tgt = torch.cat([data[lod][:, int(o[0]):int(o[0]) + re_crop, int(o[1]):int(o[1]) + re_crop].reshape(3, -1).T for o in coord])
+        sn = 2 ** max(0, 8 - lod)
+        x = O.create_decoder_input(cur[2 * fl], cur[2 * fl + 1], coord.tolist(), (sn, sn), O.step_number_of(lod, fl), lod, 6)
+        x = x + O.kernel_noise(x.shape[0], 73, 8, seed=7, offset=epoch)
+        loss = torch.nn.functional.mse_loss(O.mlp_forward(x, mlp_ref), tgt)
+        opt.zero_grad(); loss.backward(); opt.step(); sched.step()
+        O.fp_quantize_clamp(cur, fl, 8)
+        losses_ref.append(loss.item())
+    assert len(set(lods)) >= 2, lods
+    k = len(losses_ref)
+    assert np.allclose(losses_gpu[:k], np.array(losses_ref), rtol=2e-3, atol=1e-6), np.abs(losses_gpu[:k] - np.array(losses_ref)).max()
+
+
 def test_fused_adam_matches_torch_adam_with_cosine_and_clamp(dev):
     """FusedAdam (one nic_adam_multi launch per step: two lr groups, per-parameter step counts, parameters without a gradient
     skipped, clamp folded in) against torch.optim.Adam + CosineAnnealingLR + clamp_ on the CPU (image_compression.py:266-269,
@@ -1112,6 +1229,60 @@ def test_full_size_4k_properties(dev, split):
         assert_rel(p_, q_, 2e-5, "stripe: " + nme + ", split vs fp32")
     lo, hi = 1920 // 4, (1920 + sw) // 4                              # node rows of G0 the stripe touches: nothing outside them
     assert float(res[True].grad_g0[:, :lo].abs().sum()) == 0.0 and float(res[True].grad_g0[:, hi + 1:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("method", [4, 3])
+def test_full_size_video_slab_properties(dev, method):
+    """BASELINE config 4 at full size, one rank's share: the 1920 x 1080 x 64 video field (x <-> T, y <-> H, z <-> W; grids
+    [12,481,271,17] + [12,241,136,9]), rank 3 of 8 = the slab z in [720, 960), 16.6 M voxels in one launch.  Too big for the oracle
+    end to end, so: (a) 48 random 4 x 4 x 4 windows against the oracle sample for sample (in-kernel noise by global sample id),
+    (b) the loss against an independent reduction of the kernel's own output, (c) nothing outside the slab's node planes is
+    touched, (d) the chained-split mode (what bench.py --workload video times) against the fp32 kernel, (e) run to run."""
+    from neural_image_compression_v2_amd import _lib, fused
+    T, HH, WW, z0, zs = 64, 1080, 1920, 720, 240
+    g = torch.Generator().manual_seed(31)
+    g0 = torch.rand(12, WW // 4 + 1, HH // 4 + 1, T // 4 + 1, generator=g) - 0.498
+    g1 = torch.rand(12, WW // 8 + 1, HH // 8 + 1, T // 8 + 1, generator=g) - 0.498
+    assert tuple(g0.shape) == (12, 481, 271, 17) and tuple(g1.shape) == (12, 241, 136, 9)          # SURVEY 8d, config 4
+    cin = O.decoder_input_channels(12, 6, 3, method)
+    mlp = O.init_mlp(cin, 64, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    g0d, g1d = g0.to(dev), g1.to(dev)
+    ext = (T, HH, zs)
+    n = T * HH * zs
+    n_glob = T * HH * WW
+    base = 3 * n                                                        # rank-major global sample ids, like the 2D stripes
+    target = torch.rand(n, 3, generator=g).to(dev)
+    kw = dict(dim=3, method=method, step_number=0.25, mip_level=0, extent=ext, num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5,
+              noise_offset=2, sample_base=base, loss_scale=1.0 / (3.0 * n_glob), flags=_lib.NIC_FLAG_ORIGINS_ALIGNED)
+    org = [(0, 0, z0)]
+    outs = {}
+    for sp in (False, True):
+        outs[sp] = fused.fused_forward_backward(fused.PathGeometry(split_bf16=sp, **kw), g0d, g1d, org, params, target, want_y=True)
+    out = outs[True]
+    rs = np.random.RandomState(1)
+    tri = method == 3
+    for _ in range(48):
+        ox, oy, oz = int(rs.randint(0, T - 4)), int(rs.randint(0, HH - 4)), int(rs.randint(0, zs - 4))
+        idx = torch.tensor([((ox + a) * HH + (oy + b)) * zs + (oz + c) for a in range(4) for b in range(4) for c in range(4)])
+        x = O.create_decoder_input(g0, g1, [(ox, oy, z0 + oz)], (4, 4, 4), 0.25, 0, 6, method=method, use_tri_pe=tri)
+        noise = torch.stack([O.kernel_noise(1, cin, 8, seed=5, offset=2, sample_base=base + int(r))[0] for r in idx])
+        assert_rel(out.y[idx.to(dev)], O.mlp_forward(x + noise, mlp), 5e-6, "window rows")
+    loss_ind = ((out.y.double() - target.double()) ** 2).sum() / (3.0 * n_glob)
+    assert abs(float(out.loss) - float(loss_ind)) <= 1e-5 * float(loss_ind)
+    lo0, hi0 = z0 // 4, (z0 + zs) // 4                                  # G0 node planes the slab touches (grid axis 1 = z)
+    assert float(out.grad_g0[:, :lo0].abs().sum()) == 0.0 and float(out.grad_g0[:, hi0 + 1:].abs().sum()) == 0.0
+    assert float(out.grad_g1[:, :z0 // 8].abs().sum()) == 0.0 and float(out.grad_g1[:, (z0 + zs) // 8 + 1:].abs().sum()) == 0.0
+    assert float(out.grad_g0[:, lo0:hi0 + 1].abs().sum()) > 0.0
+    f32 = outs[False]
+    assert_rel(out.y, f32.y, 2e-6, "y, split vs fp32")
+    assert_rel(out.loss, f32.loss, 2e-6, "loss, split vs fp32")
+    for nme, p_, q_ in zip(["G0", "G1", "W1", "b1", "W2", "b2", "W3", "b3"], [out.grad_g0, out.grad_g1] + out.grad_mlp, [f32.grad_g0, f32.grad_g1] + f32.grad_mlp):
+        assert_rel(p_, q_, 2e-5, nme + ", split vs fp32")
+    again = fused.fused_forward_backward(fused.PathGeometry(split_bf16=True, **kw), g0d, g1d, org, params, target)
+    assert torch.equal(again.loss, out.loss)
+    for p_, q_ in zip(again.grad_mlp, out.grad_mlp):
+        assert torch.equal(p_, q_), "decoder gradients are bit-stable run to run"
 
 
 def test_kernel_noise_world_size_invariance(dev):

@@ -403,3 +403,36 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert r2.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r2.stderr
+
+
+def test_counter_based_sampler_host_functions_match_the_oracle(lib):
+    """the library's host-side sampler functions (the LOD is always drawn on the host; the origins function is the
+    host twin of the device kernel) against the oracle's restatement of the generator, and the laws the reference's draws have:
+    P(lod = k) = 3/4 4^-k clamped at MAX_MIP (image_compression.py:32-34), uniform LODs on 0..MAX_MIP (:30), origins uniform on
+    [0, data_size - crop + 1) (:40-41)."""
+    from oracle import nic_oracle as O
+    for seed in (0, 7, 0x123456789ABCDEF):
+        for step in (0, 1, 5, 1000, 2 ** 33 + 5):
+            for uni in (0, 1):
+                for mm in (0, 3, 9):
+                    assert lib.nic_sampler_lod_host(seed, step, uni, mm) == O.sampler_lod(seed, step, bool(uni), mm)
+            for dim, rng in ((2, 257), (3, 33), (2, 1)):
+                arr = (ctypes.c_int32 * (8 * dim))()
+                assert lib.nic_sampler_origins_host(seed, step, 8, dim, rng, arr) == 0
+                assert list(arr) == O.sampler_origins(seed, step, 8, dim, rng).reshape(-1).tolist()
+                assert min(arr) >= 0 and max(arr) < rng
+    n = 20000
+    lods = np.array([lib.nic_sampler_lod_host(3, s, 0, 9) for s in range(n)])
+    for k in range(4):
+        assert abs((lods == k).mean() - 0.75 * 4.0 ** -k) < 0.01
+    assert (np.array([lib.nic_sampler_lod_host(3, s, 0, 1) for s in range(2000)]) <= 1).all()
+    uni = np.array([lib.nic_sampler_lod_host(3, s, 1, 4) for s in range(n)])
+    assert all(abs((uni == k).mean() - 0.2) < 0.015 for k in range(5))
+    arr = (ctypes.c_int32 * 2)()
+    xs = []
+    for s in range(4000):
+        lib.nic_sampler_origins_host(11, s, 1, 2, 100, arr)
+        xs.append((arr[0], arr[1]))
+    xs = np.array(xs)
+    assert abs(xs.mean() - 49.5) < 1.5 and abs(np.corrcoef(xs[:, 0], xs[:, 1])[0, 1]) < 0.05
+    assert lib.nic_sampler_lod_host(0, 0, 0, -1) < 0 and lib.nic_sampler_origins_host(0, 0, 1, 2, 0, arr) < 0
