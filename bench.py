@@ -329,6 +329,19 @@ def main():
     other = "f32" if args.precision == "split" else "split"
     stat_main = kernel_only_leg(args.precision, args.stat_launches) if args.stat_launches > 0 else None
     stat_other = kernel_only_leg(other, max(args.stat_launches // 2, 10)) if args.stat_launches > 0 else None
+    # the north star's "4 x 64" decoder (5 Linear layers, 102 912 FLOP per sample) on the same grids, inputs and flags: kernel-only leg
+    stat_5 = None
+    if args.stat_launches > 0:
+        torch.manual_seed(1)
+        dec5 = ColorDecoder(CIN, HID, 5).to(dev)
+        params5 = [p.detach() for p in dec5.linear_params()]
+        flat5 = None
+        ev5 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.stat_launches // 3, 10))]
+        for j in range(3 + len(ev5)):
+            o5 = fused.fused_forward_backward(geometry(total_steps + j, "split"), g0, g1, org, params5, target, flat=flat5, events=ev5[j - 3] if j >= 3 else None)
+            flat5 = o5.flat
+        torch.cuda.synchronize()
+        stat_5 = [a.elapsed_time(b) for a, b in ev5]
 
     if rank == 0:
         mpix = n_local * world * args.steps / elapsed / 1e6
@@ -363,6 +376,17 @@ def main():
             # the other arithmetic mode on the same inputs in the same run: its median launch time carries the record
             res["roofline_" + other] = roofline_record(other, float(np.median(stat_other)), n_mine, None, {"stat_leg": pct(stat_other)})
             res["roofline_" + other]["mpix_s_kernel_only"] = round(n_mine / float(np.median(stat_other)) / 1e3, 1)
+        if stat_5:
+            f5 = 6 * (CIN * HID + 3 * HID * HID + 3 * HID)                      # 102,912
+            k5 = float(np.median(stat_5))
+            res["roofline_4x64"] = {"decoder": "Linear(73,64) + 3 x Linear(64,64) + Linear(64,3), GELU, Sigmoid (n_linear = 5)", "bound": "hbm",
+                                    "achieved": round(BYTES_PER_SAMPLE * n_mine / (k5 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(BYTES_PER_SAMPLE * n_mine / (k5 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                    "kernel": "fused_mlpn_kernel<Layout<1>, MODE_TRAIN_MSE, 5> (4 waves x 16 samples, split-bf16 products)",
+                                    "kernel_ms": round(k5, 4), "stats": {"stat_leg": pct(stat_5)}, "flop_per_sample": f5,
+                                    "mpix_s_kernel_only": round(n_mine / k5 / 1e3, 1),
+                                    "mfma_bf16": {"achieved_executed": round(3 * f5 * n_mine / (k5 * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac_executed": round(3 * f5 * n_mine / (k5 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(img)
         print(json.dumps(res), flush=True)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 3
+#define NIC_ABI_VERSION 4
 
 enum {
     NIC_OK = 0,
@@ -109,16 +109,26 @@ typedef struct nic_path_desc {
  * 8-wave x 16-sample kernel (two waves per SIMD; same arithmetic mode, different tiling and summation order).  Kept for
  * comparison runs and as the second implementation the parity tests hold the default against. */
 #define NIC_FLAG_SPLIT_TILE32 4
+/* With NIC_FLAG_SPLIT_BF16, 2D, n_linear = 3: run the step (or decode) on the depth-generic kernel that serves n_linear = 5 (4 waves per
+ * workgroup, the layer loop): the cross-check of that kernel against the dedicated 3-layer kernels. */
+#define NIC_FLAG_MLPN 8
 
-/* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}. */
+/* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
+ * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three
+ * Linear(H,H), Linear(H,3), GELU between, Sigmoid at the end (keys decoder.{0,2,4,6,8}) - supported by the fused 2D entry points with
+ * NIC_FLAG_SPLIT_BF16 (nic_fused_forward, nic_fused_forward_backward, _img, nic_fused_backward_dy); everything else returns
+ * NIC_E_UNSUPPORTED for it.  Layer i lives in w[i] / b[i]; the output layer is the last one. */
+#define NIC_MAX_LINEAR 5
 typedef struct nic_mlp {
-    const float *w[3]; /* [H,Cin], [H,H], [3,H] */
-    const float *b[3]; /* [H], [H], [3] */
+    const float *w[NIC_MAX_LINEAR]; /* [H,Cin], [H,H] x (n_linear - 2), [3,H] */
+    const float *b[NIC_MAX_LINEAR]; /* [H], [H] x (n_linear - 2), [3] */
+    int32_t n_linear;               /* 3 (0 means 3) or 5 */
+    int32_t reserved;
 } nic_mlp;
 
 typedef struct nic_mlp_grads {
-    float *w[3];
-    float *b[3];
+    float *w[NIC_MAX_LINEAR];
+    float *b[NIC_MAX_LINEAR];
 } nic_mlp_grads;
 
 int nic_abi_version(void);

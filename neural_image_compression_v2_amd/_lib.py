@@ -15,13 +15,15 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 3
+NIC_ABI_VERSION = 4
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
 NIC_FLAG_ORIGINS_ALIGNED = 1
 NIC_FLAG_SPLIT_BF16 = 2
 NIC_FLAG_SPLIT_TILE32 = 4
+NIC_FLAG_MLPN = 8
+NIC_MAX_LINEAR = 5
 
 
 class NicPathDesc(ctypes.Structure):
@@ -39,11 +41,12 @@ class NicPathDesc(ctypes.Structure):
 
 
 class NicMlp(ctypes.Structure):
-    _fields_ = [("w", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3)]
+    """struct nic_mlp: layer i in w[i] / b[i], n_linear = 3 (the reference's decoder) or 5"""
+    _fields_ = [("w", ctypes.c_void_p * 5), ("b", ctypes.c_void_p * 5), ("n_linear", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class NicMlpGrads(ctypes.Structure):
-    _fields_ = [("w", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3)]
+    _fields_ = [("w", ctypes.c_void_p * 5), ("b", ctypes.c_void_p * 5)]
 
 
 NIC_ADAM_MAX_TENSORS = 32

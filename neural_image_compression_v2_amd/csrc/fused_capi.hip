@@ -175,14 +175,27 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.noise.scale = ldexpf(1.0f, -d->num_bits);
     p.grad_scale = 2.0f * d->loss_scale;
 }
+int mlp_depth(const nic_mlp* m) { return m->n_linear == 0 ? 3 : m->n_linear; }
 void fill_mlp(FusedParams& p, const nic_mlp* m) {
-    for (int i = 0; i < 3; ++i) { p.W[i] = m->w[i]; p.b[i] = m->b[i]; }
+    for (int i = 0; i < NIC_MAX_LINEAR; ++i) { p.W[i] = m->w[i]; p.b[i] = m->b[i]; }
+    p.n_linear = mlp_depth(m);
 }
 bool mlp_ok(const nic_mlp* m) {
     if (!m) return false;
-    for (int i = 0; i < 3; ++i) if (!m->w[i] || !m->b[i]) return false;
+    const int n = mlp_depth(m);
+    if (n != 3 && n != 5) return false;
+    for (int i = 0; i < n; ++i) if (!m->w[i] || !m->b[i]) return false;
     return true;
 }
+// the depth-generic kernels serve n_linear = 5, and n_linear = 3 on request (NIC_FLAG_MLPN): 2D layouts, split-bf16 products, fp32 grids
+int use_mlpn(int layout, const nic_path_desc* d, const nic_mlp* m, bool grid_u8, bool& yes) {
+    const int n = mlp_depth(m);
+    yes = n == 5 || (d->flags & NIC_FLAG_MLPN) != 0;
+    if (!yes) return NIC_OK;
+    if ((layout != 1 && layout != 2) || !(d->flags & NIC_FLAG_SPLIT_BF16) || grid_u8) return NIC_E_UNSUPPORTED;
+    return NIC_OK;
+}
+FusedInfo info_mlpn(int n_linear) { return FusedInfo{0, mlpn_record_floats(n_linear), 16, 1, 1, 73, 4}; }
 FusedParams zero_params() {
     FusedParams p;
     ::memset(static_cast<void*>(&p), 0, sizeof(p));
@@ -206,8 +219,11 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         if (img->is_u8 && !(img->den > 0.f)) return NIC_E_ARG;
     }
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
-    const bool t16 = use_t16(layout, d);
-    const FusedInfo fi = t16 ? info_t16() : info_of(layout);
+    bool mlpn = false;
+    rc = use_mlpn(layout, d, mlp, false, mlpn);
+    if (rc) return rc;
+    const bool t16 = !mlpn && use_t16(layout, d);
+    const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout));
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise);
     fill_mlp(p, mlp);
@@ -235,6 +251,11 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY);
+    if (mlpn) {
+        rc = launch_mlpn(layout, p.n_linear, mode, p, grid, s);
+        if (rc) return rc;
+        return launch_reducen(layout, p.n_linear, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
+    }
     if (t16) {
         rc = launch_train16(layout, mode, p, grid, s);
         if (rc) return rc;
@@ -256,6 +277,7 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
         if (layout > 0) rec = info_of(layout).rec;
     }
     if (train16_record_floats() > rec) rec = train16_record_floats();
+    if (mlpn_record_floats(5) > rec) rec = mlpn_record_floats(5);
     const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float) + (1u << 20);   // one record per workgroup, at most one workgroup per CU (+ 1 MiB: diagnostic builds)
     const size_t psnr = 1024 * sizeof(double);
     return fused > psnr ? fused : psnr;
@@ -269,11 +291,19 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
-    const FusedInfo fi = info_of(layout);
+    bool mlpn = false;
+    rc = use_mlpn(layout, d, mlp, false, mlpn);
+    if (rc) return rc;
+    const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : info_of(layout);
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise);
     fill_mlp(p, mlp);
     p.y = y;
+    if (mlpn) {                                                       // one workgroup per CU (84 KB of weight images)
+        if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
+        balance_units(p, 1, 4);
+        return launch_mlpn(layout, p.n_linear, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 1, 4, d->max_workgroups), (hipStream_t)stream);
+    }
     balance_units(p, 2);
     return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);
 }
@@ -285,6 +315,7 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     int rc = check_geometry(d);
     if (rc) return rc;
     if (!g0_u8 || !g1_u8 || !origins || !mlp_ok(mlp) || (!y && !y_u8)) return NIC_E_NULL;
+    if (mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;                 // the stored-codec decode is built for the reference's 3-layer decoder
     if (d->noise_mode != NIC_NOISE_NONE) return NIC_E_ARG;            // decoding never adds noise (image_compression.py:307-346)
     if (d->num_bits < 1 || d->num_bits > 8) return NIC_E_ARG;
     const FusedInfo fi = info_of(layout);
@@ -324,7 +355,7 @@ int nic_fused_backward_dy(const nic_path_desc* d, const float* g0, const float* 
 
 int nic_decoder_forward(const nic_mlp* mlp, const float* x, int64_t n, int cin, int hidden, float* y, void* stream) {
     if (!mlp_ok(mlp) || !x || !y) return NIC_E_NULL;
-    if (hidden != kH) return NIC_E_UNSUPPORTED;
+    if (hidden != kH || mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;
     const int layout = layout_of_cin(cin);
     if (layout < 0) return layout;
     if (n < 0) return NIC_E_ARG;
@@ -338,7 +369,7 @@ int nic_decoder_forward(const nic_mlp* mlp, const float* x, int64_t n, int cin, 
 int nic_decoder_backward(const nic_mlp* mlp, const float* x, const float* dy, int64_t n, int cin, int hidden, float* dx,
                          const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
     if (!mlp_ok(mlp) || !x || !dy || !grads || !workspace) return NIC_E_NULL;
-    if (hidden != kH) return NIC_E_UNSUPPORTED;
+    if (hidden != kH || mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;
     const int layout = layout_of_cin(cin);
     if (layout < 0) return layout;
     if (n <= 0) return NIC_E_ARG;

@@ -72,8 +72,9 @@ struct FusedParams {
     float* g0_grad;
     float* g1_grad;
     const int32_t* origins;
-    const float* W[3];
-    const float* b[3];
+    const float* W[NIC_MAX_LINEAR];
+    const float* b[NIC_MAX_LINEAR];
+    int n_linear;
     NoiseSrc noise;
     const float* x;        // SRC_MEMORY: [n, cin]
     float* dx;             // SRC_MEMORY training: [n, cin] or null

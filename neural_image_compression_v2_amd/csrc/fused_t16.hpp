@@ -6,4 +6,8 @@ namespace nic {
 int launch_train16(int layout, int mode, const FusedParams& p, int grid, hipStream_t s);
 int launch_reduce16(int layout, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
 int train16_record_floats();
+// depth-generic kernels (fused_mlpn.hip)
+int launch_mlpn(int layout, int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s);
+int launch_reducen(int layout, int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+int mlpn_record_floats(int n_linear);
 }  // namespace nic

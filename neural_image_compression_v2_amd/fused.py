@@ -83,6 +83,7 @@ class PathGeometry:
     passes: int = 1                      # training steps: every crop sampled `passes` times in one launch (nic_path_desc.passes)
     split_tile32: bool = False           # with split_bf16, 2D training: the 4-wave x 32-sample kernel instead of the 8-wave x 16-sample default
     max_workgroups: int = 0              # > 0: the launch takes at most this many workgroups (concurrent fits on separate streams share the CUs)
+    mlpn: bool = False                   # 3-layer decoders on the depth-generic kernel that serves 5-layer ones (NIC_FLAG_MLPN: cross-check)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -144,6 +145,8 @@ class PathGeometry:
             d.flags |= _lib.NIC_FLAG_SPLIT_BF16
         if self.split_tile32:
             d.flags |= _lib.NIC_FLAG_SPLIT_TILE32
+        if self.mlpn:
+            d.flags |= _lib.NIC_FLAG_MLPN
         return d
 
 
@@ -193,26 +196,33 @@ def origins_aligned(geo: PathGeometry, coord) -> bool:
 
 
 def _mlp_struct(params: Sequence[torch.Tensor]) -> _lib.NicMlp:
-    """params in nn.Sequential order: W1, b1, W2, b2, W3, b3"""
+    """params in nn.Sequential order: W1, b1, W2, b2, ... (3 or 5 Linear layers)"""
     m = _lib.NicMlp()
-    for i in range(3):
+    nl = len(params) // 2
+    for i in range(nl):
         m.w[i] = params[2 * i].data_ptr()
         m.b[i] = params[2 * i + 1].data_ptr()
+    m.n_linear = nl
     return m
 
 
 def _grads_struct(grads: Sequence[Optional[torch.Tensor]]) -> _lib.NicMlpGrads:
     g = _lib.NicMlpGrads()
-    for i in range(3):
+    for i in range(len(grads) // 2):
         g.w[i] = 0 if grads[2 * i] is None else grads[2 * i].data_ptr()
         g.b[i] = 0 if grads[2 * i + 1] is None else grads[2 * i + 1].data_ptr()
     return g
 
 
 def check_mlp(params: Sequence[torch.Tensor], cin: int, hidden: int) -> List[torch.Tensor]:
-    shapes = [(hidden, cin), (hidden,), (hidden, hidden), (hidden,), (3, hidden), (3,)]
+    params = list(params)
+    if len(params) not in (6, 10):
+        raise NotImplementedError("decoders of 3 (the reference, image_compression.py:57-64) or 5 Linear layers")
+    nl = len(params) // 2
+    shapes = [(hidden, cin), (hidden,)] + [(hidden, hidden), (hidden,)] * (nl - 2) + [(3, hidden), (3,)]
+    names = [f"{k}{i + 1}" for i in range(nl) for k in ("W", "b")]
     out = []
-    for t, s, n in zip(params, shapes, ("W1", "b1", "W2", "b2", "W3", "b3")):
+    for t, s, n in zip(params, shapes, names):
         t = _lib.require_cuda_f32(t, n)
         if tuple(t.shape) != s:
             raise ValueError(f"decoder parameter {n} has shape {tuple(t.shape)}, expected {s}")
@@ -357,11 +367,11 @@ class StepOutput:
     flat: torch.Tensor                       # one buffer holding [loss | decoder grads | grid grads]
 
 
-def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor):
-    """offsets (in floats) of [loss, W1, b1, W2, b2, W3, b3, G0, G1] inside one flat gradient buffer -
+def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, n_linear: int = 3):
+    """offsets (in floats) of [loss, W1, b1, ..., Wn, bn, G0, G1] inside one flat gradient buffer -
     one buffer so that data-parallel training needs a single all-reduce per step."""
     H, cin = geo.hidden, geo.cin
-    sizes = [4, H * cin, H, H * H, H, 3 * H, 3, g0.numel(), g1.numel()]      # loss padded to 16 B
+    sizes = [4, H * cin, H] + [H * H, H] * (n_linear - 2) + [3 * H, 3, g0.numel(), g1.numel()]      # loss padded to 16 B
     offs, o = [], 0
     for s in sizes:
         offs.append(o)
@@ -392,7 +402,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
         if tuple(noise.shape) != (geo.n_samples, geo.cin):
             raise ValueError("noise must be [N, Cin]")
     dev = g0.device
-    offs, sizes, total = grad_bucket_layout(geo, g0, g1)
+    nl = len(params) // 2
+    offs, sizes, total = grad_bucket_layout(geo, g0, g1, nl)
     if flat is None:
         flat = torch.zeros(total, dtype=torch.float32, device=dev)       # grid grads must start at zero
     else:
@@ -401,8 +412,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
         flat.zero_()
     views = [flat[o:o + s] for o, s in zip(offs, sizes)]
     shapes = [p.shape for p in params]
-    gm = [views[1 + i].view(shapes[i]) for i in range(6)]
-    gg0, gg1 = views[7].view(g0.shape), views[8].view(g1.shape)
+    gm = [views[1 + i].view(shapes[i]) for i in range(2 * nl)]
+    gg0, gg1 = views[1 + 2 * nl].view(g0.shape), views[2 + 2 * nl].view(g1.shape)
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=dev) if want_y else None
     d = geo.to_desc(g0, g1, origins_aligned(geo, coord))
     lib = _lib.load()
@@ -439,8 +450,8 @@ class FusedGridMLP(torch.autograd.Function):
     the backward kernel and returns dense gradients of the grids' shapes."""
 
     @staticmethod
-    def forward(ctx, g0, g1, w1, b1, w2, b2, w3, b3, geo: PathGeometry, org: torch.Tensor, noise):
-        params = [w1, b1, w2, b2, w3, b3]
+    def forward(ctx, g0, g1, geo: PathGeometry, org: torch.Tensor, noise, *params):
+        params = list(params)
         y = fused_forward(geo, g0, g1, org, params, noise)
         ctx.save_for_backward(g0, g1, *params)
         ctx.geo, ctx.org, ctx.noise = geo, org, noise
@@ -467,8 +478,7 @@ class FusedGridMLP(torch.autograd.Function):
                                              _lib.ptr(noise), _lib.ptr(dy), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs),
                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_backward_dy")
         need = ctx.needs_input_grad
-        grads = [gg0 if need[0] else None, gg1 if need[1] else None] + [gm[i] if need[2 + i] else None for i in range(6)]
-        return (*grads, None, None, None)
+        return (gg0 if need[0] else None, gg1 if need[1] else None, None, None, None, *[gm[i] if need[5 + i] else None for i in range(len(gm))])
 
 
 def fused_grid_mlp(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -479,7 +489,7 @@ def fused_grid_mlp(geo: PathGeometry, g0, g1, coord, params, noise: Optional[tor
         noise = _lib.require_cuda_f32(noise, "noise")
     if origins_aligned(geo, coord):
         geo = dataclasses.replace(geo, flags=geo.flags | _lib.NIC_FLAG_ORIGINS_ALIGNED)
-    return FusedGridMLP.apply(g0, g1, *params, geo, org, noise)
+    return FusedGridMLP.apply(g0, g1, geo, org, noise, *params)
 
 
 class EncodeFunction(torch.autograd.Function):

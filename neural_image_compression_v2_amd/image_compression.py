@@ -31,18 +31,26 @@ class ColorDecoder(nn.Module):
     owns the parameters (state_dict keys decoder.{0,2,4}.{weight,bias}, default nn.Linear init); forward() runs the
     whole stack in one HIP kernel (nic_decoder_forward) with its own autograd backward (nic_decoder_backward)."""
 
-    def __init__(self, decoder_input_channels: int = 73, hidden_layer_channels: int = 64):
+    def __init__(self, decoder_input_channels: int = 73, hidden_layer_channels: int = 64, n_linear: int = 3):
+        """``n_linear``: 3 = the reference's decoder (depth is hard-coded there); 5 = the "4 x 64" decoder of the north star
+        (keys decoder.{0,2,4,6,8}), served by the fused 2D training step and decode."""
         super().__init__()
-        self.decoder = nn.Sequential(
-            nn.Linear(decoder_input_channels, hidden_layer_channels), nn.GELU(),
-            nn.Linear(hidden_layer_channels, hidden_layer_channels), nn.GELU(),
-            nn.Linear(hidden_layer_channels, 3), nn.Sigmoid())
+        if n_linear not in (3, 5):
+            raise NotImplementedError("3 or 5 Linear layers")
+        layers = [nn.Linear(decoder_input_channels, hidden_layer_channels), nn.GELU()]
+        for _ in range(n_linear - 2):
+            layers += [nn.Linear(hidden_layer_channels, hidden_layer_channels), nn.GELU()]
+        layers += [nn.Linear(hidden_layer_channels, 3), nn.Sigmoid()]
+        self.decoder = nn.Sequential(*layers)
+        self.n_linear = n_linear
 
     def linear_params(self) -> List[torch.Tensor]:
-        d = self.decoder
-        return [d[0].weight, d[0].bias, d[2].weight, d[2].bias, d[4].weight, d[4].bias]
+        return [t for m in self.decoder if isinstance(m, nn.Linear) for t in (m.weight, m.bias)]
 
     def forward(self, x):
+        if self.n_linear != 3:
+            raise NotImplementedError("the stand-alone decoder kernel is built for the reference's 3 layers; deeper decoders run inside the "
+                                      "fused step / decode (fused.fused_forward, fused.fused_forward_backward)")
         return fused.DecoderFunction.apply(x, *self.linear_params())
 
 
@@ -60,7 +68,7 @@ class ImageCompression:
         if seed is not None:
             torch.manual_seed(seed)
             random.seed(seed)
-        self.decoder = ColorDecoder(c.DECODER_INPUT_CHANNELS, c.HIDDEN_LAYER_CHANNELS).to(self.device)     # :350
+        self.decoder = ColorDecoder(c.DECODER_INPUT_CHANNELS, c.HIDDEN_LAYER_CHANNELS, c.DECODER_LINEAR_LAYERS).to(self.device)     # :350
         pyr = create_pyramid if c.FP_DIMENSION == 2 else create_pyramid_3d
         self.feature_pyramid, self.feature_pyramid_levels = pyr(c.FEATURE_PYRAMID_SIZE, c.FEATURE_PYRAMID_CHANNELS, c.FP_BITS,
                                                                  self.device, torch.float32, c.TF_NO_MIP)    # :352-357
@@ -202,6 +210,14 @@ class ImageCompression:
             for p, g in zip(self.decoder.linear_params(), out.grad_mlp):
                 p.grad = g
             loss = out.loss
+        elif c.DECODER_LINEAR_LAYERS != 3:
+            # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
+            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16),
+                                 noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE, noise_seed=noise_seed, noise_offset=epoch)
+            y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
+            loss = ((y - target) ** 2).mean()
+            self.optimizer.zero_grad()
+            loss.backward()
         else:
             if D == 2:
                 x = self.create_decoder_input_2d(fp, coord, c.NUM_CROPS, fl, lod)
@@ -287,6 +303,10 @@ class ImageCompression:
             fl = self.feature_pyramid_mip_levels_dict[mip_level]
             params = arc_decoder.linear_params()
             stored = fp[2 * fl].dtype == torch.uint8
+            if stored and len(params) != 6:                 # the stored-codec kernel is built for 3 layers: dequantise once (fp_load), then decode
+                from .fp_def import fp_load
+                fp = fp_load(fp, c.FP_BITS, torch.float32)
+                stored = False
             run = (lambda geo, org: fused.fused_forward_u8(geo, fp[2 * fl], fp[2 * fl + 1], org, params)) if stored else \
                   (lambda geo, org: fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], org, params))
             split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)

@@ -467,6 +467,144 @@ def test_train16_kernel_matches_the_32_sample_kernels(dev, case):
         assert torch.equal(a.loss, b.loss)
 
 
+DEEP_CASES = [
+    # extent, origins, noise, tri, mip, passes
+    ((64, 64), [(17, 101), (0, 0), (192, 192)], "tensor", True, 0, 1),
+    ((37, 21), [(3, 5), (200, 100)], "kernel", True, 0, 1),
+    ((40, 24), [(3, 5), (20, 0)], "none", False, 0, 1),
+    ((256, 256), [(0, 0), (0, 0)], "kernel", True, 0, 1),
+    ((1, 1), [(9, 9)], "kernel", True, 0, 1),
+    ((40, 24), [(3, 5), (50, 30)], "kernel", True, 1, 1),
+    ((10, 9), [(3, 5), (12, 0)], "kernel", False, 3, 1),
+    ((24, 40), [(0, 8), (100, 60)], "kernel", True, 0, 3),
+]
+
+
+@pytest.mark.parametrize("nl", [5, 3])
+@pytest.mark.parametrize("case", DEEP_CASES, ids=lambda c: f"{'x'.join(map(str, c[0]))}-{c[2]}-mip{c[4]}-p{c[5]}")
+def test_depth_generic_kernel_matches_oracle(dev, case, nl):
+    """fused_mlpn_kernel: the "4 x 64" decoder (5 Linear layers; the reference hard-codes 3, image_compression.py:57-64) through the
+    fused training step and the fused decode against the CPU oracle's autograd of the same decoder; and the same kernel at 3 layers
+    (NIC_FLAG_MLPN) against the oracle and the dedicated 3-layer kernel - tensor / in-kernel / no noise, both PEs, mips, passes,
+    a single sample, all three training entry points."""
+    from neural_image_compression_v2_amd import _lib, fused
+    extent, origins, noise_kind, tri, mip, passes = case
+    fp, _ = _pyramid(2, 64, 12, seed=19, no_mip=(mip == 0))
+    g0, g1 = fp[0], fp[1]
+    step = O.step_number_of(mip, 0)
+    g = torch.Generator().manual_seed(41)
+    mlp = O.init_mlp(73, 64, generator=g, n_linear=nl)
+    n1 = len(origins) * extent[0] * extent[1]
+    n = n1 * passes
+    target = torch.rand(n, 3, generator=g)
+    noise, nd, kw = None, None, {}
+    if noise_kind == "tensor":
+        noise = (torch.rand(n, 73, generator=g) - 0.5) / 256
+        nd = noise.to(dev)
+        kw = dict(noise_mode=_lib.NIC_NOISE_TENSOR)
+    elif noise_kind == "kernel":
+        noise = O.kernel_noise(n, 73, 8, seed=5, offset=6, sample_base=77)
+        kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5, noise_offset=6, sample_base=77)
+    listed = [o for o in origins for _ in range(passes)]                  # the oracle lists a crop `passes` times (same global sample ids)
+    ref = O.forward_backward(g0, g1, mlp, listed, extent, step, mip, target, noise, 6, use_tri_pe=tri)
+    params = [q.to(dev) for q in mlp.tensors()]
+    geo = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                             split_bf16=True, mlpn=True, passes=passes, **kw)
+    out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd, want_y=True)
+    rf = 10.0 if n >= 1000 else (100.0 if n >= 64 else 1e9)
+    assert_rel(out.y, ref.y, 5e-6, "y")
+    assert_rel(out.loss, ref.loss, 1e-5, "loss")
+    assert_rel(out.grad_g0, ref.grad_g0, 1e-4, "grad G0", row_factor=rf)
+    assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "grad G1", row_factor=rf)
+    assert len(out.grad_mlp) == 2 * nl
+    for k_, (a, b) in enumerate(zip(out.grad_mlp, ref.grad_mlp)):
+        assert_rel(a, b, 1e-4, f"decoder gradient {k_}", row_factor=rf)
+    if passes == 1:
+        assert_rel(fused.fused_forward(geo, g0.to(dev), g1.to(dev), origins, params, nd), ref.y, 5e-6, "fused decode")
+    if nl == 3:
+        geo3 = fused.PathGeometry(dim=2, method=1, step_number=step, mip_level=mip, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                                  split_bf16=True, passes=passes, **kw)
+        t16 = fused.fused_forward_backward(geo3, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd, want_y=True)
+        assert_rel(out.y, t16.y, 1e-6, "y vs the 3-layer kernel")
+        for a, b in zip([out.grad_g0, out.grad_g1] + out.grad_mlp, [t16.grad_g0, t16.grad_g1] + t16.grad_mlp):
+            assert_rel(a, b, 2e-5, "gradients vs the 3-layer kernel", row_factor=rf)
+    if noise_kind == "kernel" and mip == 0 and passes == 1 and n >= 64:
+        # the other two entry points: targets from a resident RGBX image, and an incoming dY (autograd through the fused op)
+        g0d, g1d = g0.to(dev).requires_grad_(True), g1.to(dev).requires_grad_(True)
+        pd = [q.clone().requires_grad_(True) for q in params]
+        y = fused.fused_grid_mlp(geo, g0d, g1d, origins, pd)
+        (((y - target.to(dev)) ** 2).mean()).backward()
+        assert_rel(g0d.grad, ref.grad_g0, 1e-4, "dY entry point: grad G0")
+        assert_rel(pd[2 * nl - 4].grad, ref.grad_mlp[2 * nl - 4], 1e-4, "dY entry point: last hidden weight")
+        run2 = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd)
+        assert torch.equal(run2.loss, out.loss) and all(torch.equal(a, b) for a, b in zip(run2.grad_mlp, out.grad_mlp)), "bit-stable run to run"
+
+
+def test_deep_decoder_module_and_training_loop(dev):
+    """ColorDecoder(n_linear = 5): Sequential keys decoder.{0,2,4,6,8}; a short fit through ImageCompression (fused steps, one-launch
+    Adam over 10 decoder tensors, freeze / quantise tail through the fused differentiable op, decode + PSNR) against the oracle's
+    loop on the same crops and noise; unsupported combinations fail loudly."""
+    import random
+    from neural_image_compression_v2_amd import fused
+    from neural_image_compression_v2_amd.image_compression import ColorDecoder, ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    dec = ColorDecoder(73, 64, 5)
+    assert [k for k in dec.state_dict()] == [f"decoder.{i}.{w}" for i in (0, 2, 4, 6, 8) for w in ("weight", "bias")]
+    with pytest.raises(NotImplementedError):
+        dec.to(dev)(torch.zeros(4, 73, device=dev))
+    cfg = Settings(IMAGE_SIZE=256, NUM_EPOCHS=24, NUM_CROPS=2, TF_NO_MIP=True, DECODER_LINEAR_LAYERS=5)
+    S = cfg.IMAGE_SIZE
+    gen = torch.Generator().manual_seed(12)
+    u = torch.linspace(0, 1, S)
+    img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :]
+                       for c in range(3)]) + 0.05 * (torch.rand(3, S, S, generator=gen) * 2 - 1)
+    img = O.quantize(img.clamp(0, 1), 8)
+    ic = ImageCompression(cfg, dev, seed=0)
+    ic.set_images([torch.round(img * 255).to(torch.uint8)])
+    fp_ref = [f.detach().cpu().clone() for f in ic.feature_pyramid]
+    mlp_ref = O.MLPParams.from_state_dict({k: v.detach().cpu() for k, v in ic.decoder.state_dict().items()})
+    assert len(mlp_ref.w) == 5
+    for tns in fp_ref + mlp_ref.tensors():
+        tns.requires_grad_(True)
+    opt = torch.optim.Adam([{"params": fp_ref, "lr": 0.01}, {"params": mlp_ref.tensors(), "lr": 0.005}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cfg.NUM_EPOCHS, eta_min=0)
+    torch.manual_seed(5); random.seed(5)
+    st_t, st_p = torch.get_rng_state(), random.getstate()
+    fp = ic.train_models(ic.feature_pyramid, fused_step=True)
+    losses_gpu = torch.stack(ic.loss_history).cpu().numpy()
+    torch.set_rng_state(st_t); random.setstate(st_p)
+    ocfg = O.TrainConfig(IMAGE_SIZE=256, NUM_EPOCHS=24, NUM_CROPS=2, TF_NO_MIP=True)
+    cur, frozen, acc, losses_ref = fp_ref, False, 0.0, []
+    for epoch in range(cfg.NUM_EPOCHS):
+        acc += cfg.UNIFORM_DISTRIBUTION_RATE
+        uniform = acc >= 1.0
+        if uniform:
+            acc -= 1.0
+        if epoch > cfg.NUM_EPOCHS * 0.95 and not frozen:
+            for g_ in cur:
+                g_.requires_grad = False
+            cur = O.fp_all_quantize(cur, 8)
+            frozen = True
+        inputs, coord, lod = O.random_crop_dataset([img], 256, 2, uniform, 0, 2)
+        x = O.create_decoder_input(cur[0], cur[1], coord, (256, 256), 0.25, 0, 6)
+        if epoch < cfg.NUM_EPOCHS * 0.95:
+            x = x + O.kernel_noise(x.shape[0], 73, 8, seed=7, offset=epoch)
+        loss = torch.nn.functional.mse_loss(O.mlp_forward(x, mlp_ref), inputs.reshape(-1, 3))
+        opt.zero_grad(); loss.backward(); opt.step(); sched.step()
+        O.fp_quantize_clamp(cur, 0, 8)
+        losses_ref.append(loss.item())
+    assert np.allclose(losses_gpu, np.array(losses_ref), rtol=2e-3, atol=1e-6), np.abs(losses_gpu - np.array(losses_ref)).max()
+    psnr_gpu = float(ic.psnr(fp))
+    rec = O.decode_image(cur, mlp_ref, ocfg, 0)
+    psnr_ref = float(O.calculate_psnr(O.quantize_to_bit(rec, 8), O.quantize_to_bit(img.permute(1, 2, 0), 8)))
+    assert abs(psnr_gpu - psnr_ref) < 0.01, (psnr_gpu, psnr_ref)
+    # fp32 products and the stored-codec kernel are 3-layer only: loud refusal
+    g0, g1 = ic.feature_pyramid[0].detach(), ic.feature_pyramid[1].detach()
+    geo = fused.PathGeometry(2, 1, 0.25, 0, (16, 16), 1)
+    with pytest.raises(RuntimeError):
+        fused.fused_forward(geo, g0, g1, [[0, 0]], ic.decoder.linear_params())
+
+
 def test_baseline_configs_3_to_5_at_reduced_size(dev):
     """BASELINE.json configs beyond the bench workload, as parity cases.  (3) the 33^3 colour LUT: one crop of the whole
     volume on ceil(33/4)+1 = 10 / 6-node grids, the reference's permuted weights and the textbook-trilinear switch.
