@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 4
+#define NIC_ABI_VERSION 5
 
 enum {
     NIC_OK = 0,
@@ -112,6 +112,13 @@ typedef struct nic_path_desc {
 /* With NIC_FLAG_SPLIT_BF16, 2D, n_linear = 3: run the step (or decode) on the depth-generic kernel that serves n_linear = 5 (4 waves per
  * workgroup, the layer loop): the cross-check of that kernel against the dedicated 3-layer kernels. */
 #define NIC_FLAG_MLPN 8
+/* 16-bit grid STORAGE (the reference's FP_NUM_DTYPE = 16 maps its grids to torch.float16, utils.py:301-313; its own 16-bit run does not
+ * train, readme.md:9): g0 / g1 point at bfloat16 or IEEE half arrays of the usual [C, Y, X] shape; every value is widened to fp32 in the
+ * gather and all arithmetic, the gradients (dense fp32 tensors of the grids' shapes) and the optimiser state stay fp32 - nic_adam_multi
+ * keeps an fp32 master and writes the 16-bit mirror (nic_adam_tensor.param16).  2D, NIC_FLAG_SPLIT_BF16 required:
+ * nic_fused_forward, nic_fused_forward_backward, _img, nic_fused_backward_dy. */
+#define NIC_FLAG_GRID_BF16 16
+#define NIC_FLAG_GRID_FP16 32
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
  * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three
@@ -282,6 +289,9 @@ typedef struct nic_adam_tensor {
     int64_t step;            /* 1-based step count of THIS tensor */
     double lr;
     float clamp_lo, clamp_hi; /* clamp_lo > clamp_hi: no clamp */
+    void *param16;            /* null, or a 16-bit mirror of `param` (same element count) rewritten with the rounded new values */
+    int32_t param16_kind;     /* 1: bfloat16, 2: IEEE half (round to nearest even) */
+    int32_t reserved;
 } nic_adam_tensor;
 int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
 

@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 4
+NIC_ABI_VERSION = 5
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -23,6 +23,8 @@ NIC_FLAG_ORIGINS_ALIGNED = 1
 NIC_FLAG_SPLIT_BF16 = 2
 NIC_FLAG_SPLIT_TILE32 = 4
 NIC_FLAG_MLPN = 8
+NIC_FLAG_GRID_BF16 = 16
+NIC_FLAG_GRID_FP16 = 32
 NIC_MAX_LINEAR = 5
 
 
@@ -56,7 +58,7 @@ class NicAdamTensor(ctypes.Structure):
     """struct nic_adam_tensor (include/nicv2_hip.h)."""
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("clamp_lo", ctypes.c_float),
-                ("clamp_hi", ctypes.c_float)]
+                ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class NicTargetImage(ctypes.Structure):
@@ -149,6 +151,20 @@ def require_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise NotImplementedError(f"{name} has dtype {t.dtype}; the gfx950 kernels are fp32 "
                                   "(the reference's 16-bit path is itself unfinished, readme.md:9)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+GRID_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
+
+def require_cuda_grid(t: torch.Tensor, name: str) -> torch.Tensor:
+    """grids: fp32, or 16-bit STORAGE (bfloat16 / float16; NIC_FLAG_GRID_*) - the arithmetic is fp32 either way"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} lives on {t.device}: this package only runs on a HIP device (no CPU path)")
+    if t.dtype not in GRID_DTYPES:
+        raise NotImplementedError(f"{name} has dtype {t.dtype}: grids are fp32, or bfloat16 / float16 storage")
     return t if t.is_contiguous() else t.contiguous()
 
 

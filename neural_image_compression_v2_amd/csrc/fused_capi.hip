@@ -187,10 +187,15 @@ bool mlp_ok(const nic_mlp* m) {
     for (int i = 0; i < n; ++i) if (!m->w[i] || !m->b[i]) return false;
     return true;
 }
-// the depth-generic kernels serve n_linear = 5, and n_linear = 3 on request (NIC_FLAG_MLPN): 2D layouts, split-bf16 products, fp32 grids
-int use_mlpn(int layout, const nic_path_desc* d, const nic_mlp* m, bool grid_u8, bool& yes) {
+int grid_kind_of(const nic_path_desc* d) { return (d->flags & NIC_FLAG_GRID_BF16) ? 1 : ((d->flags & NIC_FLAG_GRID_FP16) ? 2 : 0); }
+// the depth-generic kernels serve n_linear = 5, n_linear = 3 on request (NIC_FLAG_MLPN), and the decode from 16-bit grids: 2D layouts,
+// split-bf16 products
+int use_mlpn(int layout, const nic_path_desc* d, const nic_mlp* m, bool grid_u8, bool& yes, bool inference = false) {
     const int n = mlp_depth(m);
-    yes = n == 5 || (d->flags & NIC_FLAG_MLPN) != 0;
+    if ((d->flags & NIC_FLAG_GRID_BF16) && (d->flags & NIC_FLAG_GRID_FP16)) return NIC_E_ARG;
+    yes = n == 5 || (d->flags & NIC_FLAG_MLPN) != 0 || (inference && grid_kind_of(d) != 0);
+    if (grid_kind_of(d) != 0 && ((layout != 1 && layout != 2) || !(d->flags & NIC_FLAG_SPLIT_BF16) || (d->flags & NIC_FLAG_SPLIT_TILE32) || grid_u8))
+        return NIC_E_UNSUPPORTED;                                  // 16-bit grid storage: the quarter-layout 2D kernels only
     if (!yes) return NIC_OK;
     if ((layout != 1 && layout != 2) || !(d->flags & NIC_FLAG_SPLIT_BF16) || grid_u8) return NIC_E_UNSUPPORTED;
     return NIC_OK;
@@ -242,6 +247,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_den = img->is_u8 ? img->den : 1.0f;
         p.timg_rcp = 1.0f / p.timg_den;
     }
+    p.grid_kind = grid_kind_of(d);
+    if (p.grid_kind != 0 && !(mlpn || t16)) return NIC_E_UNSUPPORTED;
     p.partials = (float*)workspace;
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
     balance_units(p, 1, wpw);
@@ -292,13 +299,14 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
     bool mlpn = false;
-    rc = use_mlpn(layout, d, mlp, false, mlpn);
+    rc = use_mlpn(layout, d, mlp, false, mlpn, true);
     if (rc) return rc;
     const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : info_of(layout);
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise);
     fill_mlp(p, mlp);
     p.y = y;
+    p.grid_kind = grid_kind_of(d);
     if (mlpn) {                                                       // one workgroup per CU (84 KB of weight images)
         if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
         balance_units(p, 1, 4);

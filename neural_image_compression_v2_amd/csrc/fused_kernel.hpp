@@ -90,6 +90,7 @@ struct FusedParams {
     uint8_t* y_u8;         // [N, 3] or null: quantize_to_bit(y) as bytes (models.py:39-40)
     float dq_sub, dq_den, dq_rcp;   // uint8 grids (decode from the stored codec): value = (u - dq_sub) / dq_den (models.py:68-71)
     int grid_u8;
+    int grid_kind;                  // 0: fp32 grids; 1: bfloat16, 2: IEEE half storage, widened in the gather (fused_train16 / fused_mlpn kernels)
     float* partials;       // workspace, [n_waves][REC]
     int64_t n_total, n_per_crop, n_tiles, tiles_per_crop;   // tiles = macro-tiles of TX x TY x TZ cell blocks (SRC_MEMORY: 32 rows)
     int tiles_y, tiles_z;

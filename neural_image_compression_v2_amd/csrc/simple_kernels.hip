@@ -286,7 +286,13 @@ struct AdamEntry {
     int64_t n;
     float step_size, bc2_sqrt, lo, hi;
     int first_block;
+    uint16_t* p16;       // optional 16-bit mirror of p (NIC_FLAG_GRID_BF16 / _FP16 storage), rewritten with the rounded new value
+    int p16_kind;
 };
+__device__ __forceinline__ uint16_t to_store16(float x, int kind) {
+    if (kind == 1) return __builtin_bit_cast(uint16_t, (__bf16)x);               // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, (_Float16)x);
+}
 struct AdamTable {
     AdamEntry e[NIC_ADAM_MAX_TENSORS];
     int count;
@@ -325,6 +331,11 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
         for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
     } else {
         for (int i = threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+    }
+    if (e.p16 != nullptr) {                                       // the block re-reads its own chunk of the master (its own stores: visible to it)
+        __syncthreads();
+        uint16_t* q = e.p16 + base;
+        for (int i = threadIdx.x; i < cnt; i += 256) q[i] = to_store16(p[i], e.p16_kind);
     }
 }
 
@@ -608,6 +619,8 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, doub
         e.step_size = (float)(a.lr / bc1);        // formed in double like torch's Python-float step_size, cast once
         e.bc2_sqrt = (float)sqrt(bc2);
         e.lo = a.clamp_lo; e.hi = a.clamp_hi;
+        e.p16 = (uint16_t*)a.param16; e.p16_kind = a.param16_kind;
+        if (e.p16 != nullptr && e.p16_kind != 1 && e.p16_kind != 2) return NIC_E_ARG;
         e.first_block = (int)blocks;
         blocks += (a.n + kAdamChunk - 1) / kAdamChunk;
         if (blocks > 0x7fffffff) return NIC_E_ARG;

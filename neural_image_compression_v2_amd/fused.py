@@ -147,6 +147,12 @@ class PathGeometry:
             d.flags |= _lib.NIC_FLAG_SPLIT_TILE32
         if self.mlpn:
             d.flags |= _lib.NIC_FLAG_MLPN
+        if g0.dtype != g1.dtype:
+            raise ValueError("G0 and G1 must share a dtype")
+        if g0.dtype == torch.bfloat16:
+            d.flags |= _lib.NIC_FLAG_GRID_BF16                            # 16-bit grid STORAGE: widened in the gather, fp32 arithmetic and gradients
+        elif g0.dtype == torch.float16:
+            d.flags |= _lib.NIC_FLAG_GRID_FP16
         return d
 
 
@@ -268,8 +274,8 @@ def encode_split(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -
 @_on_tensor_device
 def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[N, 3]: encode (+ noise) + decoder in one kernel (decode_image's inner step, image_compression.py:313-345)"""
-    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
-    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    g0 = _lib.require_cuda_grid(g0.detach(), "G0")
+    g1 = _lib.require_cuda_grid(g1.detach(), "G1")
     check_grids(geo, g0, g1)
     params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
     org = upload_origins(geo, coord, g0.device, g0, g1)
@@ -384,9 +390,11 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
                            noise: Optional[torch.Tensor] = None, want_y: bool = False,
                            flat: Optional[torch.Tensor] = None, events=None) -> StepOutput:
     """One training step's forward + MSE + backward in one launch (+ the fixed-order partial reduction):
-    image_compression.py:239-265.  Gradients are returned, not accumulated into .grad."""
-    g0 = _lib.require_cuda_f32(g0.detach(), "G0")
-    g1 = _lib.require_cuda_f32(g1.detach(), "G1")
+    image_compression.py:239-265.  Gradients are returned, not accumulated into .grad.  Grids may be bfloat16 / float16 STORAGE (2D,
+    split_bf16): gathered values are widened to fp32, the returned grid gradients are fp32 tensors of the grids' shapes (feed them to
+    ``optim.FusedAdam`` on fp32 masters with ``set_mirror``)."""
+    g0 = _lib.require_cuda_grid(g0.detach(), "G0")
+    g1 = _lib.require_cuda_grid(g1.detach(), "G1")
     check_grids(geo, g0, g1)
     params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
     org = upload_origins(geo, coord, g0.device, g0, g1)

@@ -26,11 +26,19 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._clamp: Dict[int, Tuple[float, float]] = {}
+        self._mirror: Dict[int, torch.Tensor] = {}
 
     def set_clamp(self, params: Iterable[torch.Tensor], lo: float, hi: float) -> None:
         """clamp these parameters to [lo, hi] right after their update (fp_quantize_clamp, fp_def.py:227-232)"""
         for p in params:
             self._clamp[id(p)] = (float(lo), float(hi))
+
+    def set_mirror(self, param: torch.Tensor, mirror16: torch.Tensor) -> None:
+        """16-bit grid storage: ``param`` is the fp32 master the optimiser updates, ``mirror16`` a bfloat16 / float16 tensor of the same
+        shape that the same launch rewrites with the rounded new values (what the fused kernels gather from, NIC_FLAG_GRID_*)."""
+        if mirror16.dtype not in (torch.bfloat16, torch.float16) or mirror16.shape != param.shape or not mirror16.is_contiguous():
+            raise ValueError("the mirror is a contiguous bfloat16 / float16 tensor of the parameter's shape")
+        self._mirror[id(param)] = mirror16
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -63,8 +71,10 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 lo, hi = self._clamp.get(id(p), (1.0, -1.0))
+                mir = self._mirror.get(id(p))
                 entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                  p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi))
+                                                  p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi,
+                                                  0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), 0))
                 device = p.device
         for (b1, b2, eps), entries in batches.items():
             for i in range(0, len(entries), _lib.NIC_ADAM_MAX_TENSORS):

@@ -540,6 +540,75 @@ def test_depth_generic_kernel_matches_oracle(dev, case, nl):
         assert torch.equal(run2.loss, out.loss) and all(torch.equal(a, b) for a, b in zip(run2.grad_mlp, out.grad_mlp)), "bit-stable run to run"
 
 
+@pytest.mark.parametrize("nl", [3, 5])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_16_bit_grid_storage(dev, dt, nl):
+    """16-bit grid STORAGE (NIC_FLAG_GRID_BF16 / _FP16; the reference's FP_NUM_DTYPE = 16 path, utils.py:301-313): the fused step and the
+    fused decode gather from bfloat16 / float16 grids, everything else stays fp32.  Checked against the oracle run on the widened
+    grids (its precision-emulating mode: parameters rounded where the kernel rounds them), 3- and 5-layer decoders; then 6 optimiser
+    steps with fp32 masters + 16-bit mirrors (FusedAdam.set_mirror) against torch.optim.Adam on the masters with the mirrors
+    re-rounded by torch after every step."""
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.optim import FusedAdam
+    fp, _ = _pyramid(2, 64, 12, seed=23)
+    g = torch.Generator().manual_seed(3)
+    mlp = O.init_mlp(73, 64, generator=g, n_linear=nl)
+    origins, extent = [(3, 5), (120, 64), (200, 17)], (48, 40)
+    n = len(origins) * extent[0] * extent[1]
+    target = torch.rand(n, 3, generator=g)
+    kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=17, noise_offset=4)
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), split_bf16=True, **kw)
+    params = [q.to(dev) for q in mlp.tensors()]
+    m0, m1 = fp[0].to(dev), fp[1].to(dev)                                # fp32 masters
+    s0, s1 = m0.to(dt), m1.to(dt)                                        # 16-bit storage
+    noise = O.kernel_noise(n, 73, 8, seed=17, offset=4)
+    ref = O.forward_backward(s0.float().cpu(), s1.float().cpu(), mlp, origins, extent, 0.25, 0, target, noise, 6)
+    out = fused.fused_forward_backward(geo, s0, s1, origins, params, target.to(dev), want_y=True)
+    assert out.grad_g0.dtype == torch.float32 and out.grad_g0.shape == s0.shape
+    assert_rel(out.y, ref.y, 5e-6, "y")
+    assert_rel(out.loss, ref.loss, 1e-5, "loss")
+    assert_rel(out.grad_g0, ref.grad_g0, 1e-4, "grad G0")
+    assert_rel(out.grad_g1, ref.grad_g1, 1e-4, "grad G1")
+    for a, b in zip(out.grad_mlp, ref.grad_mlp):
+        assert_rel(a, b, 1e-4, "decoder gradients")
+    assert_rel(fused.fused_forward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins),
+                                                      split_bf16=True), s0, s1, origins, params),
+               O.forward_backward(s0.float().cpu(), s1.float().cpu(), mlp, origins, extent, 0.25, 0, target, None, 6, need_grad=False).y, 5e-6, "decode from 16-bit grids")
+    with pytest.raises(RuntimeError):                                    # fp32 products have no 16-bit gather
+        fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), **kw),
+                                     s0, s1, origins, params, target.to(dev))
+    # optimiser: fp32 masters, 16-bit mirrors rewritten by the same launch
+    pm = [m0.clone().requires_grad_(True), m1.clone().requires_grad_(True)]
+    mir = [s0.clone(), s1.clone()]
+    opt = FusedAdam([{"params": pm, "lr": 0.01}])
+    lo, hi = O.q_range(8)
+    opt.set_clamp(pm, lo, hi)
+    for p_, q_ in zip(pm, mir):
+        opt.set_mirror(p_, q_)
+    rm = [m0.cpu().clone().requires_grad_(True), m1.cpu().clone().requires_grad_(True)]
+    ropt = torch.optim.Adam([{"params": rm, "lr": 0.01}])
+    rmir = [s0.cpu().clone(), s1.cpu().clone()]
+    for it in range(6):
+        o_ = fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins),
+                                                             split_bf16=True, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=17, noise_offset=it),
+                                          mir[0], mir[1], origins, params, target.to(dev))
+        pm[0].grad, pm[1].grad = o_.grad_g0, o_.grad_g1
+        opt.step()
+        r_ = O.forward_backward(rmir[0].float(), rmir[1].float(), mlp, origins, extent, 0.25, 0, target, O.kernel_noise(n, 73, 8, seed=17, offset=it), 6)
+        rm[0].grad, rm[1].grad = r_.grad_g0, r_.grad_g1
+        ropt.step()
+        with torch.no_grad():
+            for r in rm:
+                r.clamp_(lo, hi)
+        rmir = [r.detach().to(dt) for r in rm]
+    for a, b, c_, d_ in zip(pm, rm, mir, rmir):
+        # Adam turns a 1e-6 gradient difference on a near-zero gradient into a visible step difference, and a mirror that rounds the other
+        # way changes the next step's gathers: the masters are held to 1 % of one step (lr 0.01, |values| <= 1/2), not to gradient precision
+        assert relmax(a.detach(), b.detach()) <= 2e-4, "fp32 masters after 6 steps"
+        assert torch.equal(c_, a.detach().to(dt)), "the mirror is the rounded master"
+        assert float((c_.float().cpu() - d_.float()).abs().max()) <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * 0.5, "mirror vs torch's rounding of its master"
+
+
 def test_deep_decoder_module_and_training_loop(dev):
     """ColorDecoder(n_linear = 5): Sequential keys decoder.{0,2,4,6,8}; a short fit through ImageCompression (fused steps, one-launch
     Adam over 10 decoder tensors, freeze / quantise tail through the fused differentiable op, decode + PSNR) against the oracle's
