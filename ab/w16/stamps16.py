@@ -33,3 +33,9 @@ print(f"waves {st.shape[0]}, total cycles/wave median {np.median(tot):.3e} (min 
 rounds = NS / 16 / (NWG * 8)
 for i, n in enumerate(names):
     print(f"{n:40s} {100 * np.median(st[:, i] / tot):6.2f} %   {np.median(st[:, i]) / rounds:9.0f} cycles/round")
+wave_id = np.arange(st.shape[0]) % 8
+for kh in (0, 1):
+    sel = (wave_id >> 2) == kh
+    print(f"-- half {kh}: total cycles/wave median {np.median(tot[sel]):.3e}")
+    for i, n in enumerate(names):
+        print(f"   {n:40s} {np.median(st[sel, i]) / rounds:9.0f} cycles/round")
