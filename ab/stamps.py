@@ -31,7 +31,13 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = geo.to_desc(fp[0], fp[1])
 ws = _lib.workspace(dev, int(_lib.load().nic_workspace_bytes(ctypes.byref(d))))
-st = ws[(8 << 20) * 4:(8 << 20) * 4 + 1024 * 16 * 8].view(torch.int64).view(1024, 16).cpu().numpy().astype(np.float64)
+KT = {1: 3, 3: 4, 4: 3}[METHOD]
+NACC = 2 * KT + 4
+PART = KT & 1
+PART16 = PART and METHOD == 1
+REC = (NACC + (4 if PART16 else 8 if PART else 0)) * 1024 + 4 * 320        # Lds<L>::REC (fused_kernel.hpp)
+off = 256 * REC * 4
+st = ws[off:off + 1024 * 16 * 8].view(torch.int64).view(1024, 16).cpu().numpy().astype(np.float64)
 names = ["0 encode+noise", "1 X^T store, L1, L2, GELUs", "2 L3, dZ3, dW3 pass, dA2", "3 dZ2^T/A1^T stores, db2", "4 wait barrier 1", "5 dW2 MFMAs",
          "6 wait barrier 2", "7 dA1, dZ1, dZ1^T store", "8 wait barrier 3", "9 dW1 MFMAs", "10 wait barrier 4", "11 dX MFMAs + grid acc",
          "12 macro-tile setup", "13 grid flush"]

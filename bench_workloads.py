@@ -107,7 +107,7 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
     tfl = flop * n / (km * 1e-3) / 1e12
     return {"metric": f"{unit[:-2]}/sec train-step (fwd+bwd + Adam + clamp), {name}", "value": round(n / dt / 1e6, 2), "unit": unit, "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("bf16x2-split chained products, f32 weight-gradient products, f32 accumulate" if (split and dim == 3)
+            "vs_baseline": None, "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate" if (split and dim == 3)
                                            else ("bf16x2-split operands, f32 accumulate" if split else "f32")),
             "data": "synthetic",
             "config": {"workload": name, "samples_per_step": n, "extent": list(extent), "grids": [list(st["g0"].shape), list(st["g1"].shape)],

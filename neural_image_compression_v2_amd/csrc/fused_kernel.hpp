@@ -178,6 +178,12 @@ enum { PREC_F32 = 0, PREC_SPLIT = 1, PREC_CHAIN = 2 };
 #ifndef NIC_DW_SB
 #define NIC_DW_SB __builtin_amdgcn_sched_barrier(0)   // keeps the one-step-ahead order of the weight-gradient loops
 #endif
+#ifndef NIC_CHAIN_DW
+#define NIC_CHAIN_DW 1        // PREC_CHAIN: the weight-gradient products too run in split bf16, their operands split on read from the fp32 images
+#endif
+#ifndef NIC_CHAIN_DW_PART
+#define NIC_CHAIN_DW_PART 1
+#endif
 #ifndef NIC_SPLIT_SB
 #define NIC_SPLIT_SB ((void)0)
 #endif
@@ -299,6 +305,16 @@ __device__ __forceinline__ lds_f* opaque(lds_f* p) {
     return p;
 }
 __device__ __forceinline__ f32x4 ld4(lds_cf* p) { return *reinterpret_cast<lds_cf4*>(p); }
+// PREC_CHAIN weight gradients: 8 consecutive samples of one row of a [feature][sample] fp32 image, split on the way to the bf16 pipe
+// (the images keep their fp32 layout and size - the [sample][feature] bf16 images of PREC_SPLIT do not fit beside 3D weights)
+struct Row8 {
+    f32x4 a, b;
+};
+__device__ __forceinline__ Row8 ld_row8(lds_cf* p) { return Row8{ld4(p), ld4(p + 4)}; }
+__device__ __forceinline__ Frag2 split_row8(const Row8& r) {
+    const float x[8] = {r.a[0], r.a[1], r.a[2], r.a[3], r.b[0], r.b[1], r.b[2], r.b[3]};
+    return split8(x);
+}
 // ds_add_f32 (no return): wave-private accumulation, workgroup scope is plenty
 __device__ __forceinline__ void lds_add(lds_f* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __host__ __device__ constexpr int ROWC(int r) { return (r & 3) + 8 * (r >> 2); }   // ROW(r,h) = ROWC(r) + 4h
@@ -1478,6 +1494,21 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         {
             lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to2 * LDT);
             lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk2 * LDT);
+            if constexpr (CHAIN && NIC_CHAIN_DW) {
+                // split on read: k-step = (source wave, samples 16h + 8u .. + 7 of lane half h); the rows of step k + 1 are in flight
+                // while step k is split and multiplied
+                Row8 aq[2], bq[2];
+                aq[0] = ld_row8(&sa_o[0]);
+                bq[0] = ld_row8(&sb_o[0]);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks + 1 < 8) {
+                        aq[(ks + 1) & 1] = ld_row8(&sa_o[((ks + 1) >> 1) * S::SCR_PER_WAVE + 8 * ((ks + 1) & 1)]);
+                        bq[(ks + 1) & 1] = ld_row8(&sb_o[((ks + 1) >> 1) * S::SCR_PER_WAVE + 8 * ((ks + 1) & 1)]);
+                    }
+                    accW2o = mfma_split(split_row8(aq[ks & 1]), split_row8(bq[ks & 1]), accW2o);
+                }
+            } else {
             f32x4 aq[2], bq[2];
             aq[0] = ld4(&sa_o[0]);
             bq[0] = ld4(&sb_o[0]);
@@ -1490,6 +1521,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accW2o = mfma32(aq[st & 1][j], bq[st & 1][j], accW2o);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
         STAMP(5);    // dW2 MFMAs (owned tile, 4 sources)
@@ -1631,6 +1663,19 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 wg_lds_barrier();
                 lds_cf* const sa_o = opaque(SCR0 + pl * LDT + 16 * h + 32 * to1 * LDT);
                 lds_cf* const sb_o = opaque(SCR0 + 64 * LDT + pl * LDT + 16 * h + 32 * tk1 * LDT);
+                if constexpr (CHAIN && NIC_CHAIN_DW) {
+                    Row8 aq[2], bq[2];
+                    aq[0] = ld_row8(&sa_o[0]);
+                    bq[0] = ld_row8(&sb_o[0]);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        if (ks + 1 < 8) {
+                            aq[(ks + 1) & 1] = ld_row8(&sa_o[((ks + 1) >> 1) * S::SCR_PER_WAVE + 8 * ((ks + 1) & 1)]);
+                            bq[(ks + 1) & 1] = ld_row8(&sb_o[((ks + 1) >> 1) * S::SCR_PER_WAVE + 8 * ((ks + 1) & 1)]);
+                        }
+                        accW1o[c2 < NCH ? c2 : 0] = mfma_split(split_row8(aq[ks & 1]), split_row8(bq[ks & 1]), accW1o[c2 < NCH ? c2 : 0]);
+                    }
+                } else {
 #pragma unroll
                 for (int src = 0; src < 4; ++src) {
 #pragma unroll
@@ -1642,10 +1687,25 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
                 wg_lds_barrier();
             } else {
                 // odd last col tile: both row tiles over this wave's own samples
                 wave_lds_fence();
+                if constexpr (CHAIN && NIC_CHAIN_DW && NIC_CHAIN_DW_PART) {
+                    const Row8 b0 = ld_row8(&sb_rd[0]), b1 = ld_row8(&sb_rd[8]);
+                    const Row8 a00 = ld_row8(&sa_rd[0]), a01 = ld_row8(&sa_rd[8]);
+                    const Row8 a10 = ld_row8(&sa_rd[32 * LDT]), a11 = ld_row8(&sa_rd[32 * LDT + 8]);
+                    const Frag2 bf0 = split_row8(b0), bf1 = split_row8(b1);
+                    // (the round's products start from zero and are added to the running sums: accumulating into accW1p directly
+                    //  crashes the compiler's 'AMDGPU Rewrite AGPR-Copy-MFMA' pass on the method-4 kernel, ROCm 7.2)
+                    f32x16 t0 = mfma_split(split_row8(a00), bf0, f32x16(0.f));
+                    f32x16 t1 = mfma_split(split_row8(a10), bf0, f32x16(0.f));
+                    t0 = mfma_split(split_row8(a01), bf1, t0);
+                    t1 = mfma_split(split_row8(a11), bf1, t1);
+                    accW1p[0] += t0;
+                    accW1p[1] += t1;
+                } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 b = ld4(&sb_rd[4 * g]);
@@ -1656,6 +1716,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                         for (int j = 0; j < 4; ++j) accW1p[to] = mfma32(a[j], b[j], accW1p[to]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 wave_lds_fence();
             }
@@ -1774,7 +1835,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     }  // macro-tile loop
 #ifdef NIC_STAMPS
     if (lane == 0) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (8u << 20)) + ((size_t)blockIdx.x * 4 + wave) * 16;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 4 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
 #pragma unroll
         for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
     }
