@@ -244,6 +244,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_cs = (int64_t)img->size[0] * p.timg_s[0];
         if (img->is_u8 < 0 || img->is_u8 > 2) return NIC_E_ARG;
         p.timg_u8 = img->is_u8;
+        if (img->is_u8 == 2 && (int64_t)img->size[0] * p.timg_s[0] >= ((int64_t)1 << 31)) return NIC_E_UNSUPPORTED;   // RGBX pixels are addressed in 32 bits
         p.timg_den = img->is_u8 ? img->den : 1.0f;
         p.timg_rcp = 1.0f / p.timg_den;
     }

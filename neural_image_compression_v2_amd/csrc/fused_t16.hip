@@ -8,6 +8,7 @@ template <class L>
 static int launch_t16(int mode, const FusedParams& p, int grid, hipStream_t s) {
     const dim3 g(grid), b(512);
     if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_train16_kernel<L, MODE_TRAIN_MSE>), g, b, 0, s, p);
+    else if (mode == MODE_TRAIN_IMG && p.timg_u8 == 2) hipLaunchKernelGGL((fused_train16_kernel<L, MODE_TRAIN_RGBX>), g, b, 0, s, p);
     else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_train16_kernel<L, MODE_TRAIN_IMG>), g, b, 0, s, p);
     else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_train16_kernel<L, MODE_TRAIN_DY>), g, b, 0, s, p);
     else return NIC_E_UNSUPPORTED;

@@ -298,6 +298,7 @@ __device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int
 #else
 #define T16_PRIO(ph) do { } while (0)
 #endif
+constexpr int MODE_TRAIN_RGBX = 4;       // this kernel's own mode: MODE_TRAIN_IMG with an interleaved uint8 RGBX target (nic_target_image.is_u8 == 2)
 template <class L, int MODE>
 __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p) {
     using S = Lds16;
@@ -456,7 +457,18 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
                 // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
                 float tgt[3] = {0.f, 0.f, 0.f};
-                if (MODE == MODE_TRAIN_IMG) {
+                if (MODE == MODE_TRAIN_RGBX) {
+                    // interleaved uint8 RGBX (one dword per pixel, fewer than 2^31 of them: checked by the host): one 32-bit offset, one load,
+                    // byte converts; u / den correctly rounded as in the planar path
+                    const uint32_t off = (uint32_t)q[0] * (uint32_t)p.timg_s[0] + (uint32_t)q[1] * (uint32_t)p.timg_s[1];
+                    const uint32_t rgbx = reinterpret_cast<const uint32_t*>(p.timg)[off];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float u = (float)((rgbx >> (8 * c)) & 255u);
+                        const float t0 = mul_rn(u, p.timg_rcp);
+                        tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
+                    }
+                } else if (MODE == MODE_TRAIN_IMG) {
                     const int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
                     uint32_t rgbx = 0u;
                     if (p.timg_u8 == 2) rgbx = reinterpret_cast<const uint32_t*>(p.timg)[off];      // interleaved: one load for the three targets
@@ -581,7 +593,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float gr;
-                    if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
+                    if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG || MODE == MODE_TRAIN_RGBX) {
                         const float diff = own ? yv[c] - tgt[c] : 0.f;
                         accLoss += diff * diff;
                         gr = p.grad_scale * diff;
