@@ -54,32 +54,44 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
 
     // ---------------- prologue: weight images (W1 in compact rho order with b1 in the column of the constant-one slot; hidden and
     // output layers with their columns in position order)
-    for (int idx = tid; idx < kH * LD; idx += 256) {
-        const int o = idx / LD, rho = idx - o * LD;
-        const int ch = channel_of_rho16(rho);
-        const float v = ch >= 0 ? p.W[0][o * L::CIN + ch] : (ch == kSlotOne ? p.b[0][o] : 0.f);
-        const __bf16 hi = (__bf16)v;
-        sm[S::OFF_W1 + idx] = hi;
-        sm[S::OFF_W1 + S::LO + idx] = (__bf16)(v - (float)hi);
-    }
+    stage_all<kH * LD, 256>(tid,
+        [&](int idx) {
+            const int o = idx / LD, rho = idx - o * LD;
+            const int ch = channel_of_rho16(rho);
+            const float* src = ch >= 0 ? &p.W[0][o * L::CIN + ch] : &p.b[0][o];
+            const float v = *src;
+            return (ch >= 0 || ch == kSlotOne) ? v : 0.f;
+        },
+        [&](int idx, float v) {
+            const __bf16 hi = (__bf16)v;
+            sm[S::OFF_W1 + idx] = hi;
+            sm[S::OFF_W1 + S::LO + idx] = (__bf16)(v - (float)hi);
+        });
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
         const float* Wk = p.W[1 + k];
-        for (int idx = tid; idx < kH * LD; idx += 256) {
-            const int o = idx / LD, ps = idx - o * LD;
-            const float v = ps < kH ? Wk[o * kH + hid16(ps)] : 0.f;
+        stage_all<kH * LD, 256>(tid,
+            [&](int idx) {
+                const int o = idx / LD, ps = idx - o * LD;
+                const float v = Wk[o * kH + hid16(ps < kH ? ps : 0)];
+                return ps < kH ? v : 0.f;
+            },
+            [&](int idx, float v) {
+                const __bf16 hi = (__bf16)v;
+                sm[S::OFF_WH + k * S::WSZ + idx] = hi;
+                sm[S::OFF_WH + k * S::WSZ + S::LO + idx] = (__bf16)(v - (float)hi);
+            });
+    }
+    stage_all<4 * LD, 256>(tid,
+        [&](int idx) {
+            const int c = idx / LD, ps = idx - c * LD;
+            return (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
+        },
+        [&](int idx, float v) {
             const __bf16 hi = (__bf16)v;
-            sm[S::OFF_WH + k * S::WSZ + idx] = hi;
-            sm[S::OFF_WH + k * S::WSZ + S::LO + idx] = (__bf16)(v - (float)hi);
-        }
-    }
-    for (int idx = tid; idx < 4 * LD; idx += 256) {
-        const int c = idx / LD, ps = idx - c * LD;
-        const float v = (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
-        const __bf16 hi = (__bf16)v;
-        sm[S::OFF_WO + idx] = hi;
-        sm[S::OFF_WO + S::WOLO + idx] = (__bf16)(v - (float)hi);
-    }
+            sm[S::OFF_WO + idx] = hi;
+            sm[S::OFF_WO + S::WOLO + idx] = (__bf16)(v - (float)hi);
+        });
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);                   // hidden biases [NH][64] in natural order, output bias [4]
     for (int idx = tid; idx < NH * kH; idx += 256) Bs[idx] = p.b[1 + idx / kH][idx % kH];
     if (tid < 4) Bs[NH * kH + tid] = tid < 3 ? p.b[NL - 1][tid] : 0.f;

@@ -313,28 +313,40 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 
     // ---------------- prologue: decoder weights -> bf16 hi / lo images (W1 in compact rho order with b1 in the column of the
     // constant-one slot; W2 / W3 columns in position order), per-wave images zeroed
-    for (int idx = tid; idx < kH * LD1; idx += 512) {
-        const int o = idx / LD1, rho = idx - o * LD1;
-        const int ch = channel_of_rho16(rho);
-        const float v = ch >= 0 ? p.W[0][o * L::CIN + ch] : (ch == kSlotOne ? p.b[0][o] : 0.f);
-        const __bf16 hi = (__bf16)v;
-        sm[S::OFF_W1 + idx] = hi;
-        sm[S::OFF_W1 + S::W1LO + idx] = (__bf16)(v - (float)hi);
-    }
-    for (int idx = tid; idx < kH * LD2; idx += 512) {
-        const int o = idx / LD2, ps = idx - o * LD2;
-        const float v = ps < kH ? p.W[1][o * kH + hid16(ps)] : 0.f;
-        const __bf16 hi = (__bf16)v;
-        sm[S::OFF_W2 + idx] = hi;
-        sm[S::OFF_W2 + S::W2LO + idx] = (__bf16)(v - (float)hi);
-    }
-    for (int idx = tid; idx < 4 * LD3; idx += 512) {
-        const int c = idx / LD3, ps = idx - c * LD3;
-        const float v = (c < 3 && ps < kH) ? p.W[2][c * kH + hid16(ps)] : 0.f;
-        const __bf16 hi = (__bf16)v;
-        sm[S::OFF_W3 + idx] = hi;
-        sm[S::OFF_W3 + S::W3LO + idx] = (__bf16)(v - (float)hi);
-    }
+    stage_all<kH * LD1, 512>(tid,
+        [&](int idx) {
+            const int o = idx / LD1, rho = idx - o * LD1;
+            const int ch = channel_of_rho16(rho);
+            const float* src = ch >= 0 ? &p.W[0][o * L::CIN + ch] : &p.b[0][o];
+            const float v = *src;
+            return (ch >= 0 || ch == kSlotOne) ? v : 0.f;
+        },
+        [&](int idx, float v) {
+            const __bf16 hi = (__bf16)v;
+            sm[S::OFF_W1 + idx] = hi;
+            sm[S::OFF_W1 + S::W1LO + idx] = (__bf16)(v - (float)hi);
+        });
+    stage_all<kH * LD2, 512>(tid,
+        [&](int idx) {
+            const int o = idx / LD2, ps = idx - o * LD2;
+            const float v = p.W[1][o * kH + hid16(ps < kH ? ps : 0)];
+            return ps < kH ? v : 0.f;
+        },
+        [&](int idx, float v) {
+            const __bf16 hi = (__bf16)v;
+            sm[S::OFF_W2 + idx] = hi;
+            sm[S::OFF_W2 + S::W2LO + idx] = (__bf16)(v - (float)hi);
+        });
+    stage_all<4 * LD3, 512>(tid,
+        [&](int idx) {
+            const int c = idx / LD3, ps = idx - c * LD3;
+            return (c < 3 && ps < kH) ? p.W[2][c * kH + hid16(ps)] : 0.f;
+        },
+        [&](int idx, float v) {
+            const __bf16 hi = (__bf16)v;
+            sm[S::OFF_W3 + idx] = hi;
+            sm[S::OFF_W3 + S::W3LO + idx] = (__bf16)(v - (float)hi);
+        });
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);                   // b2 [64] in natural order, b3 [4]
     if (tid < kH) Bs[tid] = p.b[1][tid];
     if (tid >= kH && tid < kH + 4) Bs[tid] = tid - kH < 3 ? p.b[2][tid - kH] : 0.f;
@@ -889,67 +901,64 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 
 // =====================================================================================================
 // Fixed-order reduction of the per-workgroup records of fused_train16_kernel into the decoder gradients (nn.Linear layouts) and
-// the loss.  Output index space: W1 [64][73] | b1 [64] | W2 [64][64] | b2 [64] | W3 [3][64] | b3 [3] | loss.
+// the loss.  Threads are numbered in RECORD order (kR16_SRC of them, see below): the 32 threads of a slice read 32 consecutive floats
+// of every record (the first version numbered them in output order and gathered - 4-byte reads scattered over a tile, 21 us for the
+// 21.5 MB of a 256-workgroup launch), the scattered side is the 9 092 stores.
+//   [0, 4096)      dW1 columns 0..63: tile T4 = 2 to + tk, register r, lane - partial sums of the two halves 4 x 1024 floats apart
+//   [4096, 8192)   dW2, the same
+//   [8192, 9216)   dW1 columns 64..79: row group po >> 4, register r, lane - two partial sums 4 x 256 apart
+//   [9216, 9536)   per-wave tails: db2 [64] | dW3 [3][64] | db3 [3] | loss | unused - 8 partial sums 320 apart
+constexpr int kR16_SRC = 4096 + 4096 + 1024 + 320;
 template <class L>
 __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
     using S = Lds16;
-    constexpr int N_W1 = kH * L::CIN, N_B1 = kH, N_W2 = kH * kH, N_B2 = kH, N_W3 = 3 * kH, N_B3 = 3;
-    constexpr int N_OUT = N_W1 + N_B1 + N_W2 + N_B2 + N_W3 + N_B3 + 1;
     __shared__ float red[8][32];
     const int slice = threadIdx.x >> 5;
     const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
-    const bool live = gid < N_OUT;
+    const bool live = gid < kR16_SRC;
     int nsrc = 0, off0 = 0, stride = 0;
     float* dst = nullptr;
-    // element (row i, col j) of a 32x32 accumulator tile: register (i & 3) + 4 (i >> 3) of lane j + 32 ((i >> 2) & 1)
-    auto tile32 = [](int i, int j) { return ((i & 3) + 4 * (i >> 3)) * 64 + j + 32 * ((i >> 2) & 1); };
+    bool is_loss = false;
     if (live) {
-        int t = gid;
-        if (t < N_W1 + N_B1) {
-            int o, ch;
-            if (t < N_W1) { o = t / L::CIN; ch = t - o * L::CIN; dst = gr.w[0] ? gr.w[0] + t : nullptr; }
-            else { o = t - N_W1; ch = kSlotOne; dst = gr.b[0] ? gr.b[0] + o : nullptr; }
-            const int rho = rho16_of_channel(ch), po = pos16(o);
-            if (rho < 64) {
-                const int tile = 2 * (po >> 5) + (rho >> 5);
-                off0 = S::REC_W1 + tile * 1024 + tile32(po & 31, rho & 31);
-                nsrc = 2; stride = 4 * 1024;
-            } else {
-                // 16x16 tile: row m = po & 15 -> register m & 3 of lane 16 (m >> 2) + col
-                const int m = po & 15;
-                off0 = S::REC_TAIL + (po >> 4) * 256 + (m & 3) * 64 + 16 * (m >> 2) + (rho - 64);
-                nsrc = 2; stride = 4 * 256;
-            }
-        } else if ((t -= N_W1 + N_B1) < N_W2) {
-            const int o = t / kH, k = t - o * kH;
-            const int po = pos16(o), pk = pos16(k);
-            const int tile = 2 * (po >> 5) + (pk >> 5);
-            off0 = S::REC_W2 + tile * 1024 + tile32(po & 31, pk & 31);
+        if (gid < 8192) {
+            // element of a 32x32 accumulator tile: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+            const int u = gid & 4095, T4 = u >> 10, r = (u >> 6) & 15, l = u & 63;
+            const int po = 32 * (T4 >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = 32 * (T4 & 1) + (l & 31);
+            const int o = hid16(po);
             nsrc = 2; stride = 4 * 1024;
-            dst = gr.w[1] ? gr.w[1] + t : nullptr;
-        } else if ((t -= N_W2) < N_B2) {
-            off0 = S::REC_WAVE + pos16(t); nsrc = 8; stride = 320;
-            dst = gr.b[1] ? gr.b[1] + t : nullptr;
-        } else if ((t -= N_B2) < N_W3) {
-            const int c = t / kH, k = t - c * kH;
-            off0 = S::REC_WAVE + 64 + 64 * c + pos16(k); nsrc = 8; stride = 320;
-            dst = gr.w[2] ? gr.w[2] + t : nullptr;
-        } else if ((t -= N_W3) < N_B3) {
-            off0 = S::REC_WAVE + 256 + t; nsrc = 8; stride = 320;
-            dst = gr.b[2] ? gr.b[2] + t : nullptr;
+            if (gid < 4096) {
+                off0 = S::REC_W1 + u;
+                const int ch = channel_of_rho16(col);
+                if (ch >= 0) dst = gr.w[0] ? gr.w[0] + o * L::CIN + ch : nullptr;
+                else if (ch == kSlotOne) dst = gr.b[0] ? gr.b[0] + o : nullptr;
+            } else {
+                off0 = S::REC_W2 + u;
+                dst = gr.w[1] ? gr.w[1] + o * kH + hid16(col) : nullptr;
+            }
+        } else if (gid < 9216) {
+            // 16x16 tile: register r of lane l is row r + 4 (l >> 4), column l & 15
+            const int u = gid - 8192, wq = u >> 8, r = (u >> 6) & 3, l = u & 63;
+            const int o = hid16(16 * wq + r + 4 * (l >> 4)), ch = channel_of_rho16(64 + (l & 15));
+            off0 = S::REC_TAIL + u; nsrc = 2; stride = 4 * 256;
+            if (ch >= 0) dst = gr.w[0] ? gr.w[0] + o * L::CIN + ch : nullptr;
+            else if (ch == kSlotOne) dst = gr.b[0] ? gr.b[0] + o : nullptr;
         } else {
-            off0 = S::REC_WAVE + 259; nsrc = 8; stride = 320;
-            dst = loss;
+            const int u = gid - 9216;
+            off0 = S::REC_WAVE + u; nsrc = 8; stride = 320;
+            if (u < 64) dst = gr.b[1] ? gr.b[1] + hid16(u) : nullptr;
+            else if (u < 256) dst = gr.w[2] ? gr.w[2] + ((u - 64) >> 6) * kH + hid16(u & 63) : nullptr;
+            else if (u < 259) dst = gr.b[2] ? gr.b[2] + (u - 256) : nullptr;
+            else if (u == 259) { dst = loss; is_loss = true; }
         }
     }
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
     const int per = (n_rec + 7) >> 3;
     const int w_lo = slice * per, w_hi = (w_lo + per < n_rec) ? w_lo + per : n_rec;
-    if (live) {
+    if (live && dst != nullptr) {
         for (int k = 0; k < nsrc; ++k) {
             const float* src = partials + off0 + k * stride;
             int w = w_lo;
-            for (; w + 8 <= w_hi; w += 8) {
+            for (; w + 8 <= w_hi; w += 8) {                          // (16 loads in flight per thread measured slower: 21.6 us against 14.0)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
             }
@@ -962,7 +971,7 @@ __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, in
     float acc = red[0][threadIdx.x];
 #pragma unroll
     for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
-    *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
+    *dst = is_loss ? acc * loss_scale : acc;
 }
 
 }  // namespace nic
