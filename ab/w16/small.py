@@ -10,7 +10,9 @@ S = 512
 fp, _ = fp_def.create_pyramid((S // 4, S // 4), 12, 8, dev, torch.float32, True)
 dec = ColorDecoder(73, 64).to(dev)
 params = [p.detach() for p in dec.linear_params()]
-for crops, ext in [(1, 16), (1, 64), (1, 256), (2, 256), (4, 256), (8, 256), (16, 256), (32, 256)]:
+import json
+CFG = json.loads(os.environ.get('SMALL_CFG', '[[1, 16], [1, 64], [1, 256], [2, 256], [4, 256], [8, 256], [16, 256], [32, 256]]'))
+for crops, ext in CFG:
     geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(ext, ext), num_crops=crops,
                              noise_mode=2, noise_seed=7, noise_offset=1, split_bf16=True)
     org = torch.randint(0, S - ext + 1, (crops, 2), dtype=torch.int32, device=dev)

@@ -103,11 +103,27 @@ int64_t wg_cap(int per_cu, int max_wg) {
     }
     return cap;
 }
-void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4) {
+// fused_train16 (two_seg): the macro-tiles that fill every wave a whole number of times run as whole units (segment 0), only the
+// remainder is dealt out in groups (segment 1, up to 8: a macro-tile's groups stay in one workgroup).  Setup + LDS sum + flush of a
+// unit cost that kernel 0.8 of a round (stamps: 7.6 K + 9 K cycles against 20.4 K).
+#ifndef NIC_RG_MAX_SEG
+#define NIC_RG_MAX_SEG 3
+#endif
+void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false) {
     const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
+    p.seg_split = 0;
     double best = 0.0;
+    if (two_seg) {
+        p.seg_split = p.n_tiles / waves * waves;
+        const int64_t rest = p.n_tiles - p.seg_split;
+        for (int rg = 0; rg <= NIC_RG_MAX_SEG && (p.niter >> rg) >= 1 && rest > 0; ++rg) {
+            const double cost = (double)(((rest << rg) + waves - 1) / waves) * ((double)(rounds >> rg) + 0.8);
+            if (rg == 0 || cost < best * 0.98) { best = cost; p.rg_log2 = rg; }
+        }
+        return;
+    }
     for (int rg = 0; rg <= NIC_RG_MAX && (p.niter >> rg) >= 1; ++rg) {
         const int64_t units = p.n_tiles << rg;
         const double cost = (double)((units + waves - 1) / waves) * ((double)(rounds >> rg) + 0.25);
@@ -252,9 +268,12 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (p.grid_kind != 0 && !(mlpn || t16)) return NIC_E_UNSUPPORTED;
     p.partials = (float*)workspace;
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
-    balance_units(p, 1, wpw);
+    static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
+    balance_units(p, 1, wpw, t16 && two_seg);
     if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;     // the kernels count work units in 32 bits
-    const int grid = grid_for(p.n_tiles << p.rg_log2, 1, wpw, d->max_workgroups);
+    const int64_t units_max = t16 ? (p.seg_split > ((p.n_tiles - p.seg_split) << p.rg_log2) ? p.seg_split : ((p.n_tiles - p.seg_split) << p.rg_log2))
+                                  : (p.n_tiles << p.rg_log2);
+    const int grid = grid_for(units_max, 1, wpw, d->max_workgroups);
     const int n_rec = grid;                                   // one record per workgroup
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

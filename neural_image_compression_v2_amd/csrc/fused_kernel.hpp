@@ -103,6 +103,7 @@ struct FusedParams {
     int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile and pass
     int passes;            // training: a macro-tile runs niter * passes rounds (nic_path_desc.passes); round it = pass (it / niter), sample it % niter
     int rg_log2;           // the rounds of a macro-tile are dealt out in 2^rg_log2 groups (work units): small launches balance better
+    int64_t seg_split;     // fused_train16: macro-tiles [0, seg_split) run as whole units, the rest in 2^rg_log2 groups (others: 0 = all of them in groups)
     float grad_scale;      // 2 * loss_scale
 };
 

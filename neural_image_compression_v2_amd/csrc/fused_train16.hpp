@@ -285,6 +285,9 @@ __device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int
 }
 
 // =====================================================================================================
+#ifndef NIC_T16_PREADD
+#define NIC_T16_PREADD 2          // 0: every lane flushes its own sums; 1: pre-add along x inside a wave; 2: and along y across the waves of a workgroup
+#endif
 #ifndef NIC_T16_LB
 #define NIC_T16_LB 512
 #endif
@@ -382,8 +385,17 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 
     // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave); see fused_kernel.hpp
     // (work units are counted in 32 bits: the host refuses launches with 2^30 or more of them)
+    // Two segments (balance_units): macro-tiles [0, seg_split) as whole work units - as many as fill every wave of the launch the same
+    // number of times - and the remainder dealt out in 2^rg_log2 groups of rounds, so that the last, partly filled step of a small
+    // launch costs a fraction of a unit (the reference's default step: 2 120 macro-tiles on 2 048 waves = one step of 16 rounds and
+    // 72 macro-tiles in 8 groups of 2 rounds, instead of 5 steps of 4).
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
-    const int n_units = (int)p.n_tiles << p.rg_log2;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int seg_tile0 = seg ? (int)p.seg_split : 0;
+    const int seg_tiles = seg ? (int)p.n_tiles - (int)p.seg_split : (int)p.seg_split;
+    const int rg = seg ? p.rg_log2 : 0;
+    if (seg_tiles <= 0) continue;                                       // launch-uniform
+    const int n_units = seg_tiles << rg;
     const int chunk = (((n_units + 7) >> 3) + 7) & ~7;
     const int t_begin = xcd * chunk;
     const int t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
@@ -391,16 +403,16 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
     const int base0 = t_begin + (int)(blockIdx.x >> 3) * 8;
     const int n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
     const int tiles_per_crop = (int)p.tiles_per_crop, tiles_main = (int)p.tiles_main;
-    const int rounds_unit = (p.niter * p.passes) >> p.rg_log2;
+    const int rounds_unit = (p.niter * p.passes) >> rg;
     const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);
-    const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || p.rg_log2 == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+    const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
 
     for (int kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
         const int base = base0 + (kk < n_my ? kk : 0) * lstride;
         const bool tile_ok = base + wave < t_end;
         const int unit = tile_ok ? base + wave : t_end - 1;
-        const int tile = unit >> p.rg_log2;
-        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * rounds_unit;
+        const int tile = seg_tile0 + (unit >> rg);
+        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << rg) - 1)) * rounds_unit;
         if (shift) {
             if (kk == 0) { it_begin += shift; it_len -= shift; }
             else if (kk == n_my) it_len = shift;
@@ -808,14 +820,14 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             const int ln = opaque_i(lane), g = ln >> 4;
             combine_g1_lanes16(gacc, blk_off1, blk, ln, lw);
             bool flush = true;
-            if (NIC_GROUP_SUM && p.rg_log2 > 0) {                          // launch-uniform: groups of one macro-tile sit in one workgroup
+            if (NIC_GROUP_SUM && rg > 0) {                                  // segment-uniform: groups of one macro-tile sit in one workgroup
                 lds_f* const reg0 = (lds_f*)img0;
                 constexpr int REGION = S::SPW / 2;                         // floats per wave
                 static_assert(24 * 64 <= REGION, "group-sum scratch");
                 int leader = wave;
                 if (tile_ok)
                     for (int w = wave - 1; w >= 4 * kh; --w)
-                        if (((base + w) >> p.rg_log2) == tile) leader = w;
+                        if (seg_tile0 + ((base + w) >> rg) == tile) leader = w;
                 if (leader != wave) {
                     lds_f* const mine = opaque(reg0 + wave * REGION + ln);
 #pragma unroll
@@ -826,7 +838,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 half_barrier(bar_cnt, bar_target, lane);
                 if (leader == wave && tile_ok) {
                     for (int w = wave + 1; w < 4 * kh + 4; ++w) {
-                        if (base + w >= t_end || ((base + w) >> p.rg_log2) != tile) break;
+                        if (base + w >= t_end || seg_tile0 + ((base + w) >> rg) != tile) break;
                         lds_cf* const theirs = opaque(reg0 + w * REGION + ln);
 #pragma unroll
                         for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] += theirs[i * 64];
@@ -840,6 +852,57 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #ifdef NIC_T16_NOFLUSH
             flush = false;                                                  // timing ablation only
 #endif
+            if (flush && NIC_T16_PREADD) {
+                // neighbour pre-add along x: the dx = 1 corner of cell n - 1 IS the dx = 0 corner of cell n whenever their cell offsets
+                // differ by one element (same row of the grid, no clamping in between), so the lane of quarter (1, dy) hands its 12 sums
+                // to the lane of quarter (0, dy) of the next cell and issues nothing: 34 instead of 64 atomics per channel and 16 x 1 tile
+                // (the flush is bound by the memory-side atomic units whenever many workgroups flush a small grid at the same time)
+                const int n16 = ln & 15;
+                const bool recv = g < 2;
+                const bool inb = recv ? n16 >= 1 : n16 <= 14;
+                const int partner = inb ? (recv ? ln + 31 : ln - 31) : ln;
+                const uint32_t poff = (uint32_t)__shfl((int)blk_off0, partner);
+                const bool pair = inb && (recv ? blk_off0 == poff + 1u : poff == blk_off0 + 1u);
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    const float pv = __shfl(dxacc[c >> 2][c & 3], partner);
+                    dxacc[c >> 2][c & 3] = pair ? (recv ? dxacc[c >> 2][c & 3] + pv : 0.f) : dxacc[c >> 2][c & 3];
+                }
+            }
+            if (NIC_T16_PREADD >= 2 && rg == 0) {                           // segment-uniform
+                // neighbour pre-add along y, across the waves of the workgroup: consecutive waves hold consecutive macro-tiles, i.e.
+                // rows y, y + 1, .. of the same 16 columns, and the dy = 1 corners of wave w are the dy = 0 corners of wave w + 1 whenever
+                // the cell offsets differ by one grid row.  Sums and offsets go through the wave regions of the LDS (free between the
+                // last barrier of a unit and the first store of the next): 17 x 9 instead of 8 x 34 atomics per channel and workgroup.
+                lds_f* const reg0 = (lds_f*)img0;
+                constexpr int REGION = S::SPW / 2;
+                static_assert(13 * 64 <= REGION, "pre-add scratch");
+                lds_f* const mine = opaque(reg0 + wave * REGION + ln);
+                const bool up = (g & 1) != 0;                                  // dy = 1 quarters hand over, dy = 0 quarters receive
+                ((lds_u32*)mine)[12 * 64] = blk_off0;
+                if (up) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
+                }
+                half_barrier(bar_cnt, bar_target, lane);
+                const int pw = up ? wave + 1 : wave - 1;
+                const bool inw = pw >= 0 && pw < 8;
+                lds_cf* const theirs = opaque(reg0 + (inw ? pw : wave) * REGION + (up ? ln - 16 : ln + 16));
+                const uint32_t poff = ((const lds_u32*)theirs)[12 * 64];
+                const uint32_t row = (uint32_t)p.g0.nx;
+                const bool pair = inw && (up ? poff == blk_off0 + row : blk_off0 == poff + row);
+                if (!up) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const float pv = theirs[i * 64];
+                        dxacc[i >> 2][i & 3] += pair ? pv : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] = pair ? 0.f : dxacc[i >> 2][i & 3];
+                }
+                half_barrier(bar_cnt, bar_target, lane);
+            }
             if (flush) {
                 // one predicate per lane and grid instead of one per value: a lane whose 12 sums are all exact zeros (cell outside the
                 // crop; G1 sums handed to the partner lane) issues nothing - 2 exec-mask regions per flush instead of 24
@@ -869,6 +932,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
         }
         STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
+  }  // segments
 #ifdef NIC_STAMPS
     if (lane == 0) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 8 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)

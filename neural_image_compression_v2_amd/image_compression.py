@@ -168,6 +168,11 @@ class ImageCompression:
         or the uint8 codes they were made from (``ToTensor`` = u / 255; the 3D loader = u / 256) at a quarter of the memory"""
         self.images = [im.to(self.device) for im in images]
         self._targets = [fused.TargetImage(im, den) for im in self.images]
+        if self.cfg.FP_DIMENSION == 2 and all(im.dtype == torch.uint8 and im.dim() == 3 for im in self.images):
+            # 2D uint8 codes: the fused step reads its targets from an interleaved RGBX copy of every level (one dword per sample,
+            # the 16-sample kernel's own target mode: 189 against 204 us per default step); same codes, same u / den
+            from .sampler import rgbx_interleave
+            self._targets = [fused.TargetImage(rgbx_interleave(im), den, rgbx=True) for im in self.images]
         self._sampler = None
         if self.cfg.TF_DEVICE_SAMPLER:
             # device-side sampler (sampler.py): RGBX levels built once from the level-0 codes, origins drawn on the device
