@@ -176,7 +176,7 @@ def main():
                          "image once per step and the whole gradient bucket (31 MB) is all-reduced")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
-    ap.add_argument("--workload", default="4k", choices=["4k", "lut33", "vol64", "vol128", "video", "default", "fits8"],
+    ap.add_argument("--workload", default="4k", choices=["4k", "lut33", "vol64", "vol128", "video", "default", "default3d", "fits8"],
                     help="4k (default): BASELINE configs[1], the headline; the others: bench_workloads.py (configs 3 - 5 and the reference's default "
                          "step, one GPU, same JSON shape - records for profiles/, the driver runs the default only)")
     ap.add_argument("--launch-check", action="store_true",

@@ -151,6 +151,40 @@ def _run_default(args, dev):
                          "frac": round(byt * px / dt / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "note": "whole step (host loop) over the algorithmic bytes"}}
 
 
+def _run_default3d(args, dev, method, size):
+    """the shape of the reference's own 3D sweeps (the .bat launchers: COMPRESSION_METHOD 3 / 4, IMAGE_SIZE 64 / 128, CROP_MIP_LEVEL 5):
+    8 random 32^3 crops of a resident uint8 volume per step, through the product's host loop"""
+    import random
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    cfg = Settings(IMAGE_SIZE=size, IMAGE_3D_SIZE=size, IMAGE_DIMENSION=3, COMPRESSION_METHOD=method, CROP_MIP_LEVEL=5,
+                   NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    vol = torch.randint(0, 256, (3, size, size, size), generator=g, dtype=torch.uint8)
+    ic = ImageCompression(cfg, dev, seed=0)
+    ic.set_images([vol], den=256.0)
+    torch.manual_seed(1)
+    random.seed(1)
+    for e in range(args.warmup):
+        ic.train_step(ic.feature_pyramid, e)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(args.warmup, args.warmup + args.steps):
+        ic.train_step(ic.feature_pyramid, e)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    n = cfg.NUM_CROPS * 32 ** 3
+    cin, flop, byt = _work(3, method)
+    return {"metric": f"Mvoxels/sec train-step, the reference's 3D sweep shape: 8 x 32^3 random crops of a {size}^3 volume, method {method} (host loop included)",
+            "value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"IMAGE_SIZE {size}, IMAGE_DIMENSION 3, COMPRESSION_METHOD {method}, CROP_MIP_LEVEL 5, NUM_CROPS 8, targets from the resident "
+                                   "uint8 volume, one-launch Adam", "samples_per_step": n, "cin": cin},
+            "roofline": {"bound": "hbm", "achieved": round(byt * n / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(byt * n / dt / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "note": "whole step (host loop) over the algorithmic bytes"}}
+
+
 def _run_fits8(args, dev):
     """config 5 on one GPU: 8 independent 1080p fits; concurrent on 8 streams (an eighth of the CUs each) vs back to back (whole chip each)"""
     from neural_image_compression_v2_amd import _lib, fused
@@ -228,6 +262,10 @@ def run(args):
                                     (16, 270, 480), (0, 0, 720)))
     elif w == "default":
         recs.append(_run_default(args, dev))
+    elif w == "default3d":
+        for size in (64, 128):
+            for method in (3, 4):
+                recs.append(_run_default3d(args, dev, method, size))
     elif w == "fits8":
         recs.append(_run_fits8(args, dev))
     else:

@@ -141,7 +141,7 @@ int grid_for(int64_t n_tiles, int per_cu, int waves_per_wg = 4, int max_wg = 0) 
 }
 
 void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, const float* g0, const float* g1, const int32_t* origins,
-                 const float* noise) {
+                 const float* noise, bool allow_packed = false) {
     p.d = *d;
     p.g0.p = g0; p.g0.nx = d->g0_nodes[0]; p.g0.ny = d->g0_nodes[1]; p.g0.nz = d->dim == 3 ? d->g0_nodes[2] : 1;
     p.g0.plane = (int64_t)p.g0.nx * p.g0.ny * p.g0.nz;
@@ -182,6 +182,19 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.tiles_y = ty; p.tiles_z = tz;
     p.tiles_main = (int64_t)p.full_x * ty * tz;
     p.tiles_per_crop = p.tiles_main + edge_tiles;
+    // packed tiling (the 32-sample kernels): 32 consecutive blocks of the crop's block list per macro-tile, when that needs at least
+    // 15 % fewer macro-tiles than the 16 x 2 wave blocks (block counts far from multiples of 16 and 2: small unaligned crops)
+    p.pk_nc = 0;
+    {
+        const int bz = d->dim == 3 ? blocks(ez) : 1;
+        const int64_t nc = (int64_t)bx * by * bz, pt = (nc + 31) / 32;
+        if (allow_packed && fi.tx * fi.ty * fi.tz == 32 && nc < ((int64_t)1 << 24) && pt * 115 <= p.tiles_per_crop * 100) {
+            p.pk_bx = bx; p.pk_by = by; p.pk_nc = (int)nc;
+            p.edge_lw = -1;
+            p.tiles_main = pt;
+            p.tiles_per_crop = pt;
+        }
+    }
     p.n_tiles = p.tiles_per_crop * d->num_crops;
     p.rg_log2 = 0;
     p.noise.mode = d->noise_mode;
@@ -246,7 +259,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     const bool t16 = !mlpn && use_t16(layout, d);
     const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout));
     FusedParams p = zero_params();
-    fill_encode(p, d, fi, g0, g1, origins, noise);
+    fill_encode(p, d, fi, g0, g1, origins, noise, !mlpn && !t16);
     fill_mlp(p, mlp);
     p.g0_grad = g0_grad; p.g1_grad = g1_grad;
     p.target = target; p.dy = dy; p.y = y;
@@ -323,7 +336,7 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     if (rc) return rc;
     const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : info_of(layout);
     FusedParams p = zero_params();
-    fill_encode(p, d, fi, g0, g1, origins, noise);
+    fill_encode(p, d, fi, g0, g1, origins, noise, !mlpn);
     fill_mlp(p, mlp);
     p.y = y;
     p.grid_kind = grid_kind_of(d);
@@ -348,7 +361,7 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     if (d->num_bits < 1 || d->num_bits > 8) return NIC_E_ARG;
     const FusedInfo fi = info_of(layout);
     FusedParams p = zero_params();
-    fill_encode(p, d, fi, reinterpret_cast<const float*>(g0_u8), reinterpret_cast<const float*>(g1_u8), origins, nullptr);
+    fill_encode(p, d, fi, reinterpret_cast<const float*>(g0_u8), reinterpret_cast<const float*>(g1_u8), origins, nullptr, true);
     fill_mlp(p, mlp);
     p.grid_u8 = 1;
     p.dq_sub = (float)((1 << (d->num_bits - 1)) - 1);

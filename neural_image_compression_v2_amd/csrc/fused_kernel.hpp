@@ -103,6 +103,9 @@ struct FusedParams {
     int lm, niter;         // cell block = 2^lm samples per axis (lm = max(0, -log2_step)); niter = 2^(lm * dim) rounds per macro-tile and pass
     int passes;            // training: a macro-tile runs niter * passes rounds (nic_path_desc.passes); round it = pass (it / niter), sample it % niter
     int rg_log2;           // the rounds of a macro-tile are dealt out in 2^rg_log2 groups (work units): small launches balance better
+    int pk_bx, pk_by, pk_nc;   // fused_kernel, packed tiling (pk_nc > 0): a macro-tile is 32 CONSECUTIVE cell blocks of the crop's pk_bx x pk_by x .. block
+                           // list (x fastest), pk_nc blocks per crop - crops whose block counts are far from multiples of the 16 x 2 wave block
+                           // (the 9 x 9 x 9 blocks of an unaligned 32^3 crop: 23 macro-tiles instead of 45)
     int64_t seg_split;     // fused_train16: macro-tiles [0, seg_split) run as whole units, the rest in 2^rg_log2 groups (others: 0 = all of them in groups)
     float grad_scale;      // 2 * loss_scale
 };
@@ -687,18 +690,21 @@ __device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, cons
 // axis, when it is inside the wave's block and really has the same G1 cell (clamped cells, odd alignment) - and only the
 // even-coordinate lane keeps the sum; the others are left with exact zeros, which the flush skips.
 template <class L>
-__device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, const int (&blk)[3], int lane, int lw) {
+__device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, const int (&blk)[3], int lane, int lw, const int (&pk)[3] = {0, 0, 0},
+                                                 const int (&pk_lc)[3] = {0, 0, 0}) {
     constexpr int D = L::DIM;
     static_assert(L::TX * L::TY == 32 && L::TZ == 1, "a wave block is 2^lw x 32 / 2^lw x 1 cell blocks");
-    const int T[3] = {1 << lw, 32 >> lw, 1};                  // lw = 4 for the regular tiles (TX x TY), smaller for edge tiles
-    const int STR[3] = {1, 1 << lw, 32};
+    const bool packed = pk[0] > 0;                            // packed tiling: lane pl holds block (pl + 32 tile) of the crop's list
+    const int T[3] = {packed ? pk[0] : 1 << lw, packed ? pk[1] : 32 >> lw, packed ? pk[2] : 1};   // lw = 4 for the regular tiles (TX x TY), smaller for edge tiles
+    const int STR[3] = {1, packed ? pk[0] : 1 << lw, packed ? pk[0] * pk[1] : 32};
     const int pl = lane & 31;
-    const int lc[3] = {pl & (T[0] - 1), pl >> lw, 0};
+    const int lc[3] = {packed ? pk_lc[0] : pl & (T[0] - 1), packed ? pk_lc[1] : pl >> lw, packed ? pk_lc[2] : 0};
 #pragma unroll
     for (int a = 0; a < D; ++a) {
         const bool odd = blk[a] & 1;
         const int pc = lc[a] + (odd ? -1 : 1);
-        const bool inb = pc >= 0 && pc < T[a];
+        const int ppl = pl + (odd ? -STR[a] : STR[a]);         // the partner must sit in the same wave block
+        const bool inb = pc >= 0 && pc < T[a] && ppl >= 0 && ppl < 32;
         const int partner = inb ? lane + (odd ? -STR[a] : STR[a]) : lane;
         const bool pair = inb && (uint32_t)__shfl((int)off1, partner) == off1;
 #pragma unroll
@@ -886,13 +892,21 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // ---------- macro-tile -> this lane's cell block (absolute block coordinates) and crop
         int crop = 0, lw = 4;                                       // lw: log2 of the lane block's x extent (TX = 16)
         static_assert(L::TX == 16, "lw");
-        int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0};
+        int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0}, pk_lc[3] = {0, 0, 0};
         if (SRC == SRC_ENCODE) {
             crop = (int)(tile / p.tiles_per_crop);
             int tt = (int)(tile - (int64_t)crop * p.tiles_per_crop);
             // regular tile: TX x TY blocks, x fastest (x is the grids' contiguous axis); edge tile: 2^lw x 32 / 2^lw blocks
             int boff[3];                                                          // the tile's first block inside the crop
-            if (p.edge_lw < 0 || tt < p.tiles_main) {
+            if (p.pk_nc > 0) {
+                // packed tiling: block number -> (x, y, z); numbers past the crop's list land outside the crop (masked like any such block)
+                const int ci = tt * 32 + pl;
+                const int cy = ci / p.pk_bx;
+                pk_lc[0] = ci - cy * p.pk_bx;
+                pk_lc[2] = L::DIM == 3 ? cy / p.pk_by : 0;
+                pk_lc[1] = L::DIM == 3 ? cy - pk_lc[2] * p.pk_by : cy;
+                boff[0] = boff[1] = boff[2] = 0;
+            } else if (p.edge_lw < 0 || tt < p.tiles_main) {
                 int tc[3];
                 if (L::DIM == 2) {
                     tc[1] = tt % p.tiles_y; tc[0] = tt / p.tiles_y; tc[2] = 0;
@@ -909,7 +923,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 boff[1] = e * (32 >> lw);
                 boff[0] = p.full_x * L::TX;
             }
-            const int lc[3] = {pl & ((1 << lw) - 1), pl >> lw, 0};
+            const int lc[3] = {p.pk_nc > 0 ? pk_lc[0] : pl & ((1 << lw) - 1), p.pk_nc > 0 ? pk_lc[1] : pl >> lw, p.pk_nc > 0 ? pk_lc[2] : 0};
 #pragma unroll
             for (int a = 0; a < L::DIM; ++a) {
                 org[a] = p.origins[crop * L::DIM + a];
@@ -1821,7 +1835,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         STAMP(11);   // dX MFMAs, grid-gradient accumulation
       }  // rounds of one macro-tile
         if (SRC == SRC_ENCODE && TRAIN) {
-            combine_g1_lanes<L>(gacc, blk_off1, blk, lane, lw);
+            {
+                const int pkd[3] = {p.pk_nc > 0 ? p.pk_bx : 0, p.pk_by, p.pk_nc > 0 ? p.pk_nc / (p.pk_bx * p.pk_by) : 0};
+                combine_g1_lanes<L>(gacc, blk_off1, blk, lane, lw, pkd, pk_lc);
+            }
             bool flush = true;
             // Small launches deal the rounds of a macro-tile out in groups (work units) on neighbouring waves.  Left alone, those
             // waves flush the SAME nodes in the same few thousand cycles (4 / 8 / 16 groups of the default 8 x 256^2 step: 0.35 / 0.54 /

@@ -259,8 +259,11 @@ __device__ __forceinline__ float noise_from_block(const NoiseSrc& ns, const U4& 
 // evaluations per sample, 8 on the 16-sample kernel; the generator is ~ 170 vector instructions per block).
 __device__ __forceinline__ float noise_field(const NoiseSrc& ns, const U4& b, int f) {
     const uint32_t w = block_word(b, f / 5);
-    const float u = (float)((w >> (6 * (f % 5))) & 63u);                                 // v_bfe_u32 + v_cvt_f32_u32
-    return ((u + 0.5f) * (1.0f / 64.0f) - 0.5f) * ns.scale;
+    // ((u + 0.5) / 64 - 0.5) for the 6-bit field u, without an integer-to-float convert: the field becomes the top six mantissa bits
+    // of a float in [1, 2) - m = 1 + u / 64 exactly - and m - 191 / 128 is the same (exactly representable) value: shift, and-or, add
+    const int sh = 6 * (f % 5);
+    const uint32_t bits = ((sh <= 17 ? w << (17 - sh) : w >> (sh - 17)) & 0x007E0000u) | 0x3F800000u;
+    return (__builtin_bit_cast(float, bits) - 1.4921875f) * ns.scale;
 }
 
 // ---------------------------------------------------------------------------------------------------
