@@ -94,6 +94,9 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 #ifndef NIC_RG_MAX
 #define NIC_RG_MAX 2
 #endif
+#ifndef NIC_RG_FILL
+#define NIC_RG_FILL 6
+#endif
 // workgroups a launch may use: one (two: inference) per CU, or nic_path_desc.max_workgroups when the caller shares the chip
 int64_t wg_cap(int per_cu, int max_wg) {
     int64_t cap = (int64_t)cu_count() * per_cu / 8 * 8;
@@ -124,7 +127,10 @@ void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_se
         }
         return;
     }
-    for (int rg = 0; rg <= NIC_RG_MAX && (p.niter >> rg) >= 1; ++rg) {
+    // launches that cannot give every wave one unit may go on splitting (up to 64 groups) as long as the units still fit one step:
+    // a 64^3 volume is 128 macro-tiles x 64 rounds - 8 groups fill the 1 024 waves once with 8-round units instead of half of them
+    // with 16-round units
+    for (int rg = 0; (rg <= NIC_RG_MAX || (rg <= NIC_RG_FILL && (p.n_tiles << rg) <= waves)) && (p.niter >> rg) >= 1; ++rg) {
         const int64_t units = p.n_tiles << rg;
         const double cost = (double)((units + waves - 1) / waves) * ((double)(rounds >> rg) + 0.25);
         if (rg == 0 || cost < best * 0.98) { best = cost; p.rg_log2 = rg; }     // finer only when it pays at least 2 %
