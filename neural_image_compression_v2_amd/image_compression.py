@@ -10,6 +10,7 @@ backward; every op a HIP kernel of this package) and the fused single-launch ste
 from __future__ import annotations
 
 import math
+import os
 import random
 import time
 from typing import List, Optional, Sequence
@@ -21,7 +22,7 @@ from . import _lib, fused
 from .fp_def import (create_pyramid, create_pyramid_3d, create_pyramid_mip_levels, fp_all_quantize, fp_freeze,
                      fp_quantize_clamp)
 from .models import quantize_to_bit
-from .optim import FusedAdam
+from .optim import CosineAnnealing, FusedAdam
 from .utils import calculate_psnr
 from .var2 import Settings
 
@@ -77,7 +78,7 @@ class ImageCompression:
         self.optimizer = FusedAdam([{"params": self.feature_pyramid, "lr": 0.01},
                                     {"params": self.decoder.parameters(), "lr": 0.005}])                   # :361-364
         self.optimizer.set_clamp(self.feature_pyramid, -(2 ** c.FP_BITS - 1) / 2 ** (c.FP_BITS + 1), 0.5)  # fp_def.py:227-232
-        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365
+        self.scheduler = CosineAnnealing(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365 (torch's CosineAnnealingLR, bit for bit, without its overhead)
         self.images: List[torch.Tensor] = []
         self.loss_history: List[torch.Tensor] = []
         self.step_count = 0
@@ -209,12 +210,24 @@ class ImageCompression:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
                                  noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16))
-            out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target)
-            self.optimizer.zero_grad(set_to_none=True)
+            if isinstance(target, fused.TargetImage) and not os.environ.get("NIC_NO_PLAN"):
+                # the steady state: one prepared launch plan (and one reused gradient bucket) per (level, LOD)
+                plans = self.__dict__.setdefault("_plans", {})
+                plan = plans.get((fl, lod))
+                lin = self.decoder.linear_params()
+                if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
+                    plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
+                out = plan.run(coord, geo.noise_mode, noise_seed, epoch)
+            else:
+                flats = self.__dict__.setdefault("_flat", {})      # one gradient bucket per level, reused: the optimiser's launch table stays valid
+                out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl))
+                flats[fl] = out.flat
+            for t in fp:                                           # optimizer.zero_grad(set_to_none=True) without its hooks: the other levels must not step
+                t.grad = None
             fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1
             for p, g in zip(self.decoder.linear_params(), out.grad_mlp):
                 p.grad = g
-            loss = out.loss
+            loss = out.loss.clone()                                # the bucket (and the loss slot in it) is rewritten by the next step
         elif c.DECODER_LINEAR_LAYERS != 3:
             # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16),

@@ -436,3 +436,20 @@ def test_counter_based_sampler_host_functions_match_the_oracle(lib):
     xs = np.array(xs)
     assert abs(xs.mean() - 49.5) < 1.5 and abs(np.corrcoef(xs[:, 0], xs[:, 1])[0, 1]) < 0.05
     assert lib.nic_sampler_lod_host(0, 0, 0, -1) < 0 and lib.nic_sampler_origins_host(0, 0, 1, 2, 0, arr) < 0
+
+
+def test_light_cosine_scheduler_is_torchs_bit_for_bit():
+    """optim.CosineAnnealing replaces torch's CosineAnnealingLR in the training loop (70 us of host time per step): the learning rates
+    of both groups must be the same doubles over whole schedules, including steps past T_max (the restart branch)."""
+    import torch
+    from neural_image_compression_v2_amd.optim import CosineAnnealing
+    for T in (1, 7, 100, 1000):
+        ps = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))]
+        mk = lambda: torch.optim.SGD([{"params": [ps[0]], "lr": 0.01}, {"params": [ps[1]], "lr": 0.005}])
+        o_ref, o_new = mk(), mk()
+        ref = torch.optim.lr_scheduler.CosineAnnealingLR(o_ref, T_max=T, eta_min=0)
+        new = CosineAnnealing(o_new, T_max=T, eta_min=0)
+        for step in range(2 * T + 5):
+            o_ref.step(); ref.step(); new.step()
+            assert ref.get_last_lr() == new.get_last_lr(), (T, step, ref.get_last_lr(), new.get_last_lr())
+            assert [g["lr"] for g in o_ref.param_groups] == [g["lr"] for g in o_new.param_groups]
