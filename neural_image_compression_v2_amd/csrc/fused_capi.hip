@@ -107,10 +107,11 @@ int64_t wg_cap(int per_cu, int max_wg) {
     return cap;
 }
 // fused_train16 (two_seg): the macro-tiles that fill every wave a whole number of times run as whole units (segment 0), only the
-// remainder is dealt out in groups (segment 1, up to 8: a macro-tile's groups stay in one workgroup).  Setup + LDS sum + flush of a
+// remainder is dealt out in groups (segment 1, up to 16 = single rounds: 8 crops 188 -> 174 us against 8 groups, although a macro-tile's
+// groups then sit in two workgroups and flush twice).  Setup + LDS sum + flush of a
 // unit cost that kernel 0.8 of a round (stamps: 7.6 K + 9 K cycles against 20.4 K).
 #ifndef NIC_RG_MAX_SEG
-#define NIC_RG_MAX_SEG 3
+#define NIC_RG_MAX_SEG 4
 #endif
 void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false) {
     const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
