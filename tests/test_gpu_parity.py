@@ -1345,6 +1345,62 @@ def test_fused_adam_matches_torch_adam_with_cosine_and_clamp(dev):
     o_chk.load_state_dict(sd)
 
 
+def test_fused_adam_reused_launch_table_and_light_scheduler(dev):
+    """The training loop's steady state: gradients land in the SAME buffers every step, so FusedAdam reuses the launch table of the previous
+    step (only step counts and learning rates are rewritten), and the loop's scheduler is optim.CosineAnnealing.  Same checks as the
+    test above against torch.optim.Adam + CosineAnnealingLR on the CPU; a parameter that gains / loses its gradient, a changed clamp and
+    a loaded state must each fall back to the full path."""
+    from neural_image_compression_v2_amd.optim import CosineAnnealing, FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(12, 9, 7), (12, 5, 4), (64, 73), (64,), (3, 64), (3,), (515,)]
+    ref = [(torch.rand(*sh, generator=g) - 0.5).requires_grad_(True) for sh in shapes]
+    prod = [r.detach().clone().to(dev).requires_grad_(True) for r in ref]
+    steps = 14
+    o_ref = torch.optim.Adam([{"params": ref[:2] + ref[6:], "lr": 0.01}, {"params": ref[2:6], "lr": 0.005}])
+    o_prod = FusedAdam([{"params": prod[:2] + prod[6:], "lr": 0.01}, {"params": prod[2:6], "lr": 0.005}])
+    s_ref = torch.optim.lr_scheduler.CosineAnnealingLR(o_ref, T_max=steps, eta_min=0)
+    s_prod = CosineAnnealing(o_prod, T_max=steps, eta_min=0)
+    lo, hi = -(2 ** 8 - 1) / 2 ** 9, 0.5
+    o_prod.set_clamp(prod[:2], lo, hi)
+    bufs = [torch.zeros_like(q) for q in prod]                   # the loop's reused gradient buffers
+    fast = 0
+    for it in range(steps):
+        for k, (r, q) in enumerate(zip(ref, prod)):
+            if k == 6 and it in (4, 5, 9):                       # another level's grid: loses and regains its gradient
+                r.grad, q.grad = None, None
+                continue
+            gr = torch.randn(*r.shape, generator=g) * 0.2
+            r.grad = gr.clone()
+            bufs[k].copy_(gr.to(dev))
+            q.grad = bufs[k]
+        if it == 11:
+            o_prod.set_clamp(prod[:1], lo, 0.25)                 # a changed clamp invalidates the table
+        was = getattr(o_prod, "_cache", None) is not None
+        o_ref.step(); s_ref.step()
+        o_prod.step(); s_prod.step()
+        fast += int(was and getattr(o_prod, "_cache", None) is not None)
+        with torch.no_grad():
+            ref[0].clamp_(lo, 0.25 if it >= 11 else hi)
+            ref[1].clamp_(lo, hi)
+        assert s_ref.get_last_lr() == s_prod.get_last_lr()
+    assert fast >= 6, fast                                       # the reuse path did run
+    for k, (r, q) in enumerate(zip(ref, prod)):
+        assert_rel(q.detach(), r.detach(), 2e-6, f"fused adam (reused table) tensor {k}")
+    assert int(o_prod.state[prod[6]]["step"]) == steps - 3 and int(o_prod.state[prod[0]]["step"]) == steps
+    sd = o_prod.state_dict()
+    o_prod.load_state_dict(sd)                                   # replaces the state tensors: the next step must not use the old table
+    assert getattr(o_prod, "_cache", None) is None
+    for k, q in enumerate(prod):
+        q.grad = bufs[k]
+    for r, b in zip(ref, bufs):
+        r.grad = b.cpu().clone()
+    o_ref.step(); o_prod.step()
+    with torch.no_grad():
+        ref[0].clamp_(lo, 0.25); ref[1].clamp_(lo, hi)
+    for k, (r, q) in enumerate(zip(ref, prod)):
+        assert_rel(q.detach(), r.detach(), 2e-6, f"after load_state_dict, tensor {k}")
+
+
 # ------------------------------------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize("split", [False, True], ids=["f32", "split"])
 def test_full_size_4k_properties(dev, split):
