@@ -6,6 +6,7 @@ ulp); everything downstream of the decoder MLP is held to the north-star's 1e-3 
 ~1e-5 (fp32 matrix cores with fp32 accumulate; only the summation orders differ from the CPU BLAS).
 """
 import math
+import dataclasses
 import os
 
 import numpy as np
@@ -1188,6 +1189,24 @@ def test_targets_from_the_resident_image(dev):
             assert_rel(out.grad_g1, ref.grad_g1, 1e-6, what)
         with pytest.raises(IndexError):
             fused.fused_forward_backward(geo, g0, g1, [[isz[0] - ext[0] + 1] + [0] * (dim - 1)] * len(orgs), params, fused.TargetImage(img_f))
+        # the training loop's prepared launch (fused.StepPlan): the same step, steps in a row with changing origins and noise offsets
+        timg = fused.TargetImage(img_u8, den)
+        plan = fused.StepPlan(geo, g0, g1, params, timg)
+        assert plan.matches(g0, g1, params, timg) and not plan.matches(g0.clone(), g1, params, timg)
+        for k, shift in enumerate((0, 1, 2)):
+            o2 = [[max(0, v - shift) for v in o] for o in orgs]
+            g2 = dataclasses.replace(geo, noise_offset=9 + k)
+            want = fused.fused_forward_backward(g2, g0, g1, o2, params, timg)
+            got = plan.run(torch.tensor(o2), g2.noise_mode, g2.noise_seed, g2.noise_offset)
+            assert_rel(got.loss, want.loss, 1e-6, "StepPlan loss")
+            for a, b in zip(got.grad_mlp, want.grad_mlp):
+                assert_rel(a, b, 1e-6, "StepPlan decoder gradients")
+            assert_rel(got.grad_g0, want.grad_g0, 1e-6, "StepPlan G0")
+            assert_rel(got.grad_g1, want.grad_g1, 1e-6, "StepPlan G1")
+        with pytest.raises(IndexError):
+            plan.run([[isz[0] - ext[0] + 1] + [0] * (dim - 1)] * len(orgs), geo.noise_mode, 3, 9)
+        with pytest.raises(IndexError):
+            plan.run([[-1] + [0] * (dim - 1)] * len(orgs), geo.noise_mode, 3, 9)
 
 
 def test_device_sampler_and_rgbx_targets(dev):
