@@ -291,8 +291,10 @@ typedef struct nic_adam_tensor {
     float clamp_lo, clamp_hi; /* clamp_lo > clamp_hi: no clamp */
     void *param16;            /* null, or a 16-bit mirror of `param` (same element count) rewritten with the rounded new values */
     int32_t param16_kind;     /* 1: bfloat16, 2: IEEE half (round to nearest even) */
-    int32_t reserved;
+    int32_t flags;            /* NIC_ADAM_ZERO_GRAD: the launch also zeroes `grad` (written through the const pointer) once it has been read - the
+                                 gradient bucket of an atomically accumulating step is clean for the next step without a fill kernel; 0 otherwise */
 } nic_adam_tensor;
+#define NIC_ADAM_ZERO_GRAD 1
 int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
 
 #ifdef __cplusplus

@@ -52,13 +52,14 @@ class NicMlpGrads(ctypes.Structure):
 
 
 NIC_ADAM_MAX_TENSORS = 32
+NIC_ADAM_ZERO_GRAD = 1
 
 
 class NicAdamTensor(ctypes.Structure):
     """struct nic_adam_tensor (include/nicv2_hip.h)."""
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("clamp_lo", ctypes.c_float),
-                ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class NicTargetImage(ctypes.Structure):

@@ -288,6 +288,7 @@ struct AdamEntry {
     int first_block;
     uint16_t* p16;       // optional 16-bit mirror of p (NIC_FLAG_GRID_BF16 / _FP16 storage), rewritten with the rounded new value
     int p16_kind;
+    int zero_g;          // NIC_ADAM_ZERO_GRAD: the gradient is zeroed once read (an atomically accumulated bucket is clean for the next step)
 };
 __device__ __forceinline__ uint16_t to_store16(float x, int kind) {
     if (kind == 1) return __builtin_bit_cast(uint16_t, (__bf16)x);               // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -327,10 +328,17 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
             adam_one(pp.z, gg.z, mm.z, vv.z, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
             adam_one(pp.w, gg.w, mm.w, vv.w, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
             reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+            if (e.zero_g) reinterpret_cast<float4*>(const_cast<float*>(g))[i] = float4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) {
+            adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            if (e.zero_g) const_cast<float*>(g)[i] = 0.f;
+        }
     } else {
-        for (int i = threadIdx.x; i < cnt; i += 256) adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
+            if (e.zero_g) const_cast<float*>(g)[i] = 0.f;
+        }
     }
     if (e.p16 != nullptr) {                                       // the block re-reads its own chunk of the master (its own stores: visible to it)
         __syncthreads();
@@ -620,6 +628,8 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, doub
         e.bc2_sqrt = (float)sqrt(bc2);
         e.lo = a.clamp_lo; e.hi = a.clamp_hi;
         e.p16 = (uint16_t*)a.param16; e.p16_kind = a.param16_kind;
+        if (a.flags & ~NIC_ADAM_ZERO_GRAD) return NIC_E_ARG;
+        e.zero_g = (a.flags & NIC_ADAM_ZERO_GRAD) ? 1 : 0;
         if (e.p16 != nullptr && e.p16_kind != 1 && e.p16_kind != 2) return NIC_E_ARG;
         e.first_block = (int)blocks;
         blocks += (a.n + kAdamChunk - 1) / kAdamChunk;

@@ -453,6 +453,8 @@ class StepPlan:
     of a step drops from ~60 to ~15 us (the reference's default step is host-bound: 8 x 256^2 samples take the GPU 0.21 ms).
     Targets: a resident :class:`TargetImage`.  Origins: a host tensor / list (validated) or a device int32 tensor (taken as is)."""
 
+    LOSS_SLOTS = 1 << 16
+
     def __init__(self, geo: PathGeometry, g0, g1, params, target: "TargetImage"):
         if not isinstance(target, TargetImage):
             raise TypeError("StepPlan reads its targets from a resident TargetImage")
@@ -466,8 +468,12 @@ class StepPlan:
         offs, sizes, total = grad_bucket_layout(geo, self.g0, self.g1, nl)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
         views = [self.flat[o:o + s] for o, s in zip(offs, sizes)]
-        self.loss = views[0][0]
-        self.loss_ptr = _lib.ptr(views[0])
+        # the loss of step k goes to slot k % LOSS_SLOTS of a buffer of its own: the value a step returns stays valid (for 65 536 steps)
+        # without a copy out of the reused bucket (the copy kernel was 4.7 us of a 218 us step)
+        self.loss_buf = torch.zeros(self.LOSS_SLOTS, dtype=torch.float32, device=self.dev)
+        self.loss_base = self.loss_buf.data_ptr()
+        self.steps = 0
+        self.clean = False                   # True: the grid-gradient part of the bucket is known to be zero (the decoder part is overwritten)
         self.gm = [views[1 + i].view(self.params[i].shape) for i in range(2 * nl)]
         self.gg0, self.gg1 = views[1 + 2 * nl].view(self.g0.shape), views[2 + 2 * nl].view(self.g1.shape)
         self.d = geo.to_desc(self.g0, self.g1, False)
@@ -509,17 +515,21 @@ class StepPlan:
                     if min(col) < 0 or max(col) > self.hi[a]:
                         raise IndexError(f"axis {a}: crop origin {min(col)}..{max(col)} outside [0, {self.hi[a]}] (image / grid bounds)")
                 org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
+            slot = self.steps % self.LOSS_SLOTS
+            self.steps += 1
             d = self.d
             d.noise_mode = int(noise_mode)
             d.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
             d.noise_offset = int(noise_offset) & 0xFFFFFFFFFFFFFFFF
-            self.flat.zero_()
+            if not self.clean:
+                self.flat.zero_()
+            self.clean = False               # set again by whoever zeroes the grid gradients (FusedAdam.zero_grad_in_step: in its own launch)
             ws = _lib.workspace(dev, int(self.lib.nic_workspace_bytes(ctypes.byref(d))))
             _lib.check(self.lib.nic_fused_forward_backward_img(
                 ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
-                self.loss_ptr, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
                 "nic_fused_forward_backward_img")
-        return StepOutput(self.loss, None, self.gg0, self.gg1, self.gm, self.flat)
+        return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ class ImageCompression:
         self.optimizer = FusedAdam([{"params": self.feature_pyramid, "lr": 0.01},
                                     {"params": self.decoder.parameters(), "lr": 0.005}])                   # :361-364
         self.optimizer.set_clamp(self.feature_pyramid, -(2 ** c.FP_BITS - 1) / 2 ** (c.FP_BITS + 1), 0.5)  # fp_def.py:227-232
+        self.optimizer.zero_grad_in_step(self.feature_pyramid)      # the grids' gradient buckets are zeroed by the Adam launch itself
         self.scheduler = CosineAnnealing(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365 (torch's CosineAnnealingLR, bit for bit, without its overhead)
         self.images: List[torch.Tensor] = []
         self.loss_history: List[torch.Tensor] = []
@@ -206,6 +207,7 @@ class ImageCompression:
             fl = self.feature_pyramid_mip_levels_dict[lod]
             target = inputs.reshape(-1, 3)
         noisy = epoch < c.NUM_EPOCHS * 0.95
+        plan_used = None
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
@@ -218,6 +220,7 @@ class ImageCompression:
                 if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
                     plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
                 out = plan.run(coord, geo.noise_mode, noise_seed, epoch)
+                plan_used = plan
             else:
                 flats = self.__dict__.setdefault("_flat", {})      # one gradient bucket per level, reused: the optimiser's launch table stays valid
                 out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl))
@@ -227,7 +230,7 @@ class ImageCompression:
             fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1
             for p, g in zip(self.decoder.linear_params(), out.grad_mlp):
                 p.grad = g
-            loss = out.loss.clone()                                # the bucket (and the loss slot in it) is rewritten by the next step
+            loss = out.loss if out.loss.data_ptr() != out.flat.data_ptr() else out.loss.clone()   # a slot of the reused bucket is rewritten by the next step
         elif c.DECODER_LINEAR_LAYERS != 3:
             # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16),
@@ -250,6 +253,8 @@ class ImageCompression:
             self.optimizer.zero_grad()
             loss.backward()
         self.optimizer.step()                             # Adam of both groups + the clamp of :269, one launch
+        if plan_used is not None and isinstance(self.optimizer, FusedAdam):
+            plan_used.clean = True                        # .. which also zeroed the grid gradients of the bucket it read
         self.scheduler.step()
         if not isinstance(self.optimizer, FusedAdam):
             fp_quantize_clamp(fp, fl, c.FP_BITS)                                                       # :269

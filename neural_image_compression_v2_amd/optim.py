@@ -27,6 +27,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._clamp: Dict[int, Tuple[float, float]] = {}
         self._mirror: Dict[int, torch.Tensor] = {}
+        self._zero: set = set()
 
     def load_state_dict(self, state_dict) -> None:
         self._cache = None                                       # the state tensors are replaced
@@ -35,6 +36,13 @@ class FusedAdam(torch.optim.Optimizer):
     def add_param_group(self, param_group) -> None:
         self._cache = None
         super().add_param_group(param_group)
+
+    def zero_grad_in_step(self, params: Iterable[torch.Tensor]) -> None:
+        """the launch that updates these parameters also zeroes their gradient buffers (``NIC_ADAM_ZERO_GRAD``): the bucket a fused step
+        accumulates into with atomics is clean for the next step without a fill kernel (``fused.StepPlan.clean``)"""
+        for p in params:
+            self._zero.add(id(p))
+        self._cache = None
 
     def set_clamp(self, params: Iterable[torch.Tensor], lo: float, hi: float) -> None:
         """clamp these parameters to [lo, hi] right after their update (fp_quantize_clamp, fp_def.py:227-232)"""
@@ -84,7 +92,8 @@ class FusedAdam(torch.optim.Optimizer):
                 mir = self._mirror.get(id(p))
                 entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                   p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi,
-                                                  0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), 0))
+                                                  0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2),
+                                                  _lib.NIC_ADAM_ZERO_GRAD if id(p) in self._zero else 0))
                 device = p.device
         for (b1, b2, eps), entries in batches.items():
             for i in range(0, len(entries), _lib.NIC_ADAM_MAX_TENSORS):

@@ -1381,6 +1381,7 @@ def test_fused_adam_reused_launch_table_and_light_scheduler(dev):
     s_prod = CosineAnnealing(o_prod, T_max=steps, eta_min=0)
     lo, hi = -(2 ** 8 - 1) / 2 ** 9, 0.5
     o_prod.set_clamp(prod[:2], lo, hi)
+    o_prod.zero_grad_in_step(prod[:2])                           # NIC_ADAM_ZERO_GRAD: the launch zeroes these gradient buffers once read
     bufs = [torch.zeros_like(q) for q in prod]                   # the loop's reused gradient buffers
     fast = 0
     for it in range(steps):
@@ -1398,6 +1399,7 @@ def test_fused_adam_reused_launch_table_and_light_scheduler(dev):
         o_ref.step(); s_ref.step()
         o_prod.step(); s_prod.step()
         fast += int(was and getattr(o_prod, "_cache", None) is not None)
+        assert float(bufs[0].abs().max()) == 0.0 and float(bufs[1].abs().max()) == 0.0 and float(bufs[2].abs().max()) > 0.0
         with torch.no_grad():
             ref[0].clamp_(lo, 0.25 if it >= 11 else hi)
             ref[1].clamp_(lo, hi)
