@@ -94,6 +94,9 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
 #ifndef NIC_RG_MAX
 #define NIC_RG_MAX 2
 #endif
+#ifndef NIC_RG_SEG0
+#define NIC_RG_SEG0 3        // segment 0 may use 8 groups (a macro-tile's groups then sit in two workgroups and flush twice)
+#endif
 #ifndef NIC_RG_FILL
 #define NIC_RG_FILL 6
 #endif
@@ -113,10 +116,11 @@ int64_t wg_cap(int per_cu, int max_wg) {
 #ifndef NIC_RG_MAX_SEG
 #define NIC_RG_MAX_SEG 4
 #endif
-void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false) {
+void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false, bool allow_seg0 = false, int rg0_max = NIC_RG_MAX) {
     const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
+    p.rg0_log2 = 0;
     p.seg_split = 0;
     double best = 0.0;
     if (two_seg) {
@@ -128,13 +132,32 @@ void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_se
         }
         return;
     }
-    // launches that cannot give every wave one unit may go on splitting (up to 64 groups) as long as the units still fit one step:
-    // a 64^3 volume is 128 macro-tiles x 64 rounds - 8 groups fill the 1 024 waves once with 8-round units instead of half of them
-    // with 16-round units
-    for (int rg = 0; (rg <= NIC_RG_MAX || (rg <= NIC_RG_FILL && (p.n_tiles << rg) <= waves)) && (p.niter >> rg) >= 1; ++rg) {
-        const int64_t units = p.n_tiles << rg;
-        const double cost = (double)((units + waves - 1) / waves) * ((double)(rounds >> rg) + 0.25);
-        if (rg == 0 || cost < best * 0.98) { best = cost; p.rg_log2 = rg; }     // finer only when it pays at least 2 %
+    // The 32-sample kernels (mlpn_two_seg: fused_mlpn keeps one segment): segment 0 = the macro-tiles that fill every wave a whole number of
+    // times when dealt out in 2^rg0 groups (rg0 <= NIC_RG_MAX: the groups of a macro-tile stay in one workgroup), segment 1 = the remainder in
+    // 2^rg1 groups, where launches that cannot give every wave one unit may go on splitting (up to 64 groups) as long as the units still fit
+    // one step: a 64^3 volume is 128 macro-tiles x 64 rounds - 8 groups fill the 1 024 waves once with 8-round units; the 8 x 23 packed
+    // macro-tiles of the reference's 3D sweeps run as one step of 8-round units (128 macro-tiles) + one of 4-round units (56).
+    auto rest_cost = [&](int64_t rest, int& rg_best) {
+        double bc = 0.0;
+        rg_best = 0;
+        for (int rg = 0; (rg <= NIC_RG_MAX || (rg <= NIC_RG_FILL && (rest << rg) <= waves)) && (p.niter >> rg) >= 1; ++rg) {
+            const double cost = (double)(((rest << rg) + waves - 1) / waves) * ((double)(rounds >> rg) + 0.25);
+            if (rg == 0 || cost < bc * 0.98) { bc = cost; rg_best = rg; }          // finer only when it pays at least 2 %
+        }
+        return bc;
+    };
+    int rg1 = 0;
+    best = rest_cost(p.n_tiles, rg1);                                             // one segment
+    p.rg_log2 = rg1;
+    p.rg0_log2 = 0;
+    if (!allow_seg0) return;
+    for (int rg0 = 0; rg0 <= rg0_max && (p.niter >> rg0) >= 1; ++rg0) {
+        const int64_t full = (p.n_tiles << rg0) / waves;
+        if (full == 0) continue;
+        const int64_t t0 = (full * waves) >> rg0, rest = p.n_tiles - t0;
+        int r1 = 0;
+        const double cost = (double)full * ((double)(rounds >> rg0) + 0.25) + (rest > 0 ? rest_cost(rest, r1) : 0.0);
+        if (cost < best * 0.98) { best = cost; p.seg_split = t0; p.rg0_log2 = rg0; p.rg_log2 = r1; }
     }
 }
 
@@ -289,10 +312,12 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     p.partials = (float*)workspace;
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
     static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
-    balance_units(p, 1, wpw, t16 && two_seg);
-    if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;     // the kernels count work units in 32 bits
-    const int64_t units_max = t16 ? (p.seg_split > ((p.n_tiles - p.seg_split) << p.rg_log2) ? p.seg_split : ((p.n_tiles - p.seg_split) << p.rg_log2))
-                                  : (p.n_tiles << p.rg_log2);
+    // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes - pay for method 4's 24 + 48 sums per lane: the
+    //  reference's 3D sweep shape 0.368 -> 0.332 ms; not for method 3's 48 + 48: 0.454 -> 0.475 ms)
+    balance_units(p, 1, wpw, t16 && two_seg, !t16 && !mlpn && two_seg, layout == 3 ? NIC_RG_MAX : NIC_RG_SEG0);
+    const int64_t units0 = p.seg_split << p.rg0_log2, units1 = (p.n_tiles - p.seg_split) << p.rg_log2;
+    const int64_t units_max = units0 > units1 ? units0 : units1;
+    if (units_max >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;                    // the kernels count work units in 32 bits
     const int grid = grid_for(units_max, 1, wpw, d->max_workgroups);
     const int n_rec = grid;                                   // one record per workgroup
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;

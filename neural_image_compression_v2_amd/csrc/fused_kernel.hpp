@@ -106,7 +106,8 @@ struct FusedParams {
     int pk_bx, pk_by, pk_nc;   // fused_kernel, packed tiling (pk_nc > 0): a macro-tile is 32 CONSECUTIVE cell blocks of the crop's pk_bx x pk_by x .. block
                            // list (x fastest), pk_nc blocks per crop - crops whose block counts are far from multiples of the 16 x 2 wave block
                            // (the 9 x 9 x 9 blocks of an unaligned 32^3 crop: 23 macro-tiles instead of 45)
-    int64_t seg_split;     // fused_train16: macro-tiles [0, seg_split) run as whole units, the rest in 2^rg_log2 groups (others: 0 = all of them in groups)
+    int64_t seg_split;     // macro-tiles [0, seg_split) run in 2^rg0_log2 groups of rounds (fused_train16: whole units), the rest in 2^rg_log2 groups; 0 = one segment
+    int rg0_log2;
     float grad_scale;      // 2 * loss_scale
 };
 
@@ -853,10 +854,6 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     // ---------------- XCD-aware persistent walk, in workgroup-synchronous rounds of 4 tiles (one per wave)
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
     // work unit = (macro-tile, group of rounds); units of one macro-tile are consecutive, so they land on the waves of one workgroup
-    const int64_t n_units = p.n_tiles << p.rg_log2;
-    const int64_t chunk = (((n_units + 7) >> 3) + 3) & ~(int64_t)3;      // a multiple of 4: the groups of a macro-tile stay in one workgroup
-    const int64_t t_begin = xcd * chunk;
-    const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
     const int lstride = nb8 * 4;
 
 #ifdef NIC_STAMPS
@@ -872,19 +869,31 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     // Workgroups therefore run in four phases: phase f starts its first unit at round f * rounds / 4 and comes back for the rounds it
     // skipped after its last unit (one extra, partial unit: same work for every wave, no idle time), which keeps the phases
     // f * rounds / 4 apart for the whole launch.
+    // Two segments (balance_units): macro-tiles [0, seg_split) dealt out in 2^rg0_log2 groups of rounds - as many of them as fill every
+    // wave of the launch a whole number of times - and the remainder in 2^rg_log2 (usually more) groups, so that the last, partly filled
+    // step of a small launch costs a fraction of a unit.  seg_split = 0: one segment, as before.
+  for (int seg = 0; seg < 2; ++seg) {
+    const int64_t seg_tile0 = seg ? p.seg_split : 0;
+    const int64_t seg_tiles = seg ? p.n_tiles - p.seg_split : p.seg_split;
+    const int rg = seg ? p.rg_log2 : p.rg0_log2;
+    if (seg_tiles <= 0) continue;                                        // launch-uniform
+    const int64_t n_units = seg_tiles << rg;
+    const int64_t chunk = (((n_units + 7) >> 3) + 3) & ~(int64_t)3;      // a multiple of 4: the groups of a macro-tile stay in one workgroup
+    const int64_t t_begin = xcd * chunk;
+    const int64_t t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
     const int64_t base0 = t_begin + (int64_t)(blockIdx.x >> 3) * 4;
     const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
-    const int rounds_unit = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> p.rg_log2;
+    const int rounds_unit = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> rg;
     const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);      // phases (a power of two)
-    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && (NIC_STAGGER_RG || p.rg_log2 == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
     for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
         const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
         // last tile with every lane masked, which contributes exact zeros everywhere
         const bool tile_ok = base + wave < t_end;
         const int64_t unit = tile_ok ? base + wave : t_end - 1;
-        const int64_t tile = unit >> p.rg_log2;
-        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << p.rg_log2) - 1)) * rounds_unit;
+        const int64_t tile = seg_tile0 + (unit >> rg);
+        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << rg) - 1)) * rounds_unit;
         if (shift) {
             if (kk == 0) { it_begin += shift; it_len -= shift; }          // the first unit without its first `shift` rounds ..
             else if (kk == n_my) it_len = shift;                         // .. which are done at the very end
@@ -1846,12 +1855,12 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             // free between the last barrier of a unit and the first store of the next - and the lowest wave flushes for all.
             constexpr int GV = GridAcc<L>::NG0 + GridAcc<L>::K1 * (kC / 2);
             constexpr int REGION = SPLIT ? S::SPW / 2 : S::SCR_PER_WAVE;                  // floats per wave
-            if (NIC_GROUP_SUM && GV * 64 <= REGION && p.rg_log2 > 0) {                     // launch-uniform
+            if (NIC_GROUP_SUM && GV * 64 <= REGION && rg > 0) {                            // segment-uniform
                 lds_f* const reg0 = sm + (SPLIT ? S::OFF_IMG : S::OFF_SCR);
                 int leader = wave;
                 if (tile_ok)
                     for (int w = wave - 1; w >= 0; --w)
-                        if (((base + w) >> p.rg_log2) == tile) leader = w;
+                        if (seg_tile0 + ((base + w) >> rg) == tile) leader = w;
                 if (leader != wave) {
                     lds_f* const mine = opaque(reg0 + wave * REGION + lane);
 #pragma unroll
@@ -1862,7 +1871,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 wg_lds_barrier();
                 if (leader == wave && tile_ok) {
                     for (int w = wave + 1; w < 4; ++w) {
-                        if (base + w >= t_end || ((base + w) >> p.rg_log2) != tile) break;
+                        if (base + w >= t_end || seg_tile0 + ((base + w) >> rg) != tile) break;
                         lds_cf* const theirs = opaque(reg0 + w * REGION + lane);
 #pragma unroll
                         for (int i = 0; i < GridAcc<L>::NG0; ++i) gacc.g0[i] += theirs[i * 64];
@@ -1877,6 +1886,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         }
         STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
+  }  // segments
 #ifdef NIC_STAMPS
     if (lane == 0) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 4 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
