@@ -312,9 +312,9 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     p.partials = (float*)workspace;
     const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
     static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
-    // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes - pay for method 4's 24 + 48 sums per lane: the
-    //  reference's 3D sweep shape 0.368 -> 0.332 ms; not for method 3's 48 + 48: 0.454 -> 0.475 ms)
-    balance_units(p, 1, wpw, t16 && two_seg, !t16 && !mlpn && two_seg, layout == 3 ? NIC_RG_MAX : NIC_RG_SEG0);
+    // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes: the reference's 3D sweep shape 0.368 -> 0.332 ms with
+    //  method 4; method 3, twice the sums per lane, lost 5 % until its flush pre-added neighbouring sums and gains 6 % since)
+    balance_units(p, 1, wpw, t16 && two_seg, !t16 && !mlpn && two_seg, NIC_RG_SEG0);
     const int64_t units0 = p.seg_split << p.rg0_log2, units1 = (p.n_tiles - p.seg_split) << p.rg_log2;
     const int64_t units_max = units0 > units1 ? units0 : units1;
     if (units_max >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;                    // the kernels count work units in 32 bits

@@ -716,6 +716,56 @@ __device__ __forceinline__ void combine_g1_lanes(GridAcc<L>& ga, uint32_t off1, 
     }
 }
 
+// Neighbour pre-add of the G0 sums before the flush (2D and method 3: a lane half is one dx): the dx = 1 corners of block n - 1 are the
+// dx = 0 corners of block n whenever the two cell offsets differ by one element, the dy = 1 corners of a block are the dy = 0 corners of
+// the block one grid row up - inside a 16 x 2 wave block that is the lane 16 further (packed tiling: bx further).  A lane hands such sums
+// to the lane that addresses the same nodes and issues nothing for them: 17 x 3 instead of 32 x 4 node visits per channel and wave block
+// in 2D.  The offset tests reject clamped cells, row wraps and blocks of other crops.  Method 4's tetrahedra share no corner along x or y.
+#ifndef NIC_PREADD32
+#define NIC_PREADD32 1
+#endif
+template <class L>
+__device__ __forceinline__ void preadd_g0_lanes(GridAcc<L>& ga, uint32_t off0, int lane, int str_y, uint32_t row) {
+    if (!NIC_PREADD32 || (L::DIM == 3 && L::K0 == 4)) return;
+    constexpr int NG0 = GridAcc<L>::NG0, E = NG0 / kC;
+    const int pl = lane & 31, h = lane >> 5;
+    {   // x: lane (pl, h = 1) -> lane (pl + 1, h = 0), same corner index e
+        const bool recv = h == 0;
+        const bool inb = recv ? pl >= 1 : pl <= 30;
+        const int partner = inb ? (recv ? lane + 31 : lane - 31) : lane;
+        const uint32_t poff = (uint32_t)__shfl((int)off0, partner);
+        const bool pair = inb && (recv ? off0 == poff + 1u : poff == off0 + 1u);
+#pragma unroll
+        for (int i = 0; i < NG0; ++i) {
+            const float pv = __shfl(ga.g0[i], partner);
+            ga.g0[i] = pair ? (recv ? ga.g0[i] + pv : 0.f) : ga.g0[i];
+        }
+    }
+    {   // y: corner e with dy = 1 of lane pl -> corner e - (dy bit) of lane pl + str_y (same half)
+        const bool has_up = pl + str_y < 32, has_dn = pl - str_y >= 0;
+        const uint32_t off_up = (uint32_t)__shfl((int)off0, has_up ? lane + str_y : lane);
+        const uint32_t off_dn = (uint32_t)__shfl((int)off0, has_dn ? lane - str_y : lane);
+        const bool send = has_up && off_up == off0 + row, recv = has_dn && off0 == off_dn + row;
+        constexpr int DYB = L::DIM == 2 ? 1 : 2;              // the dy bit of the corner index e
+        float pv[NG0 / 2];
+#pragma unroll
+        for (int e = 0, k = 0; e < E; ++e) {
+            if (!(e & DYB)) continue;
+#pragma unroll
+            for (int c = 0; c < kC; ++c, ++k) pv[k] = __shfl(ga.g0[e * kC + c], has_dn ? lane - str_y : lane);
+        }
+#pragma unroll
+        for (int e = 0, k = 0; e < E; ++e) {
+            if (!(e & DYB)) continue;
+#pragma unroll
+            for (int c = 0; c < kC; ++c, ++k) {
+                ga.g0[(e ^ DYB) * kC + c] += recv ? pv[k] : 0.f;
+                ga.g0[e * kC + c] = send ? 0.f : ga.g0[e * kC + c];
+            }
+        }
+    }
+}
+
 // one fp32 atomic per (corner, channel) of the lane's cell; exact zeros (cells outside the crop, zero weights) are skipped
 template <class L>
 __device__ __forceinline__ void flush_grid_grads(const FusedParams& p, uint32_t off0, uint32_t off1, int h, const GridAcc<L>& ga) {
@@ -1882,7 +1932,10 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                 wg_lds_barrier();
                 flush = leader == wave;
             }
-            if (flush) flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+            if (flush) {
+                preadd_g0_lanes<L>(gacc, blk_off0, lane, p.pk_nc > 0 ? p.pk_bx : (1 << lw), (uint32_t)p.g0.nx);
+                flush_grid_grads<L>(p, blk_off0, blk_off1, h, gacc);
+            }
         }
         STAMP(13);   // grid-gradient flush (atomics)
     }  // macro-tile loop
