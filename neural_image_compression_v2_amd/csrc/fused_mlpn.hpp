@@ -536,6 +536,11 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                 wg_lds_barrier();
                 flush = leader == wave;
             }
+            if (flush && NIC_T16_PREADD) preadd_x16(dxacc, blk_off0, ln);
+            if (NIC_T16_PREADD >= 2 && p.rg_log2 == 0) {                    // launch-uniform
+                static_assert(13 * 64 <= S::SPW / 2, "pre-add scratch");
+                preadd_y16<4>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, S::SPW / 2, [&]() { wg_lds_barrier(); });
+            }
             if (flush) {
                 const uint32_t pb0 = (uint32_t)p.g0.plane * 4u, pb1 = (uint32_t)p.g1.plane * 4u;
                 uint32_t nz0 = 0u, nz1 = 0u;

@@ -253,6 +253,57 @@ __device__ __forceinline__ void combine_g1_lanes16(GridAcc16& ga, uint32_t off1,
     }
 }
 
+// Neighbour pre-add of a quarter-layout kernel's G0 sums along x, inside a wave: the dx = 1 corner of cell n - 1 IS the dx = 0 corner of
+// cell n whenever their cell offsets differ by one element (same row of the grid, no clamping in between), so the lane of quarter (1, dy)
+// hands its 12 sums to the lane of quarter (0, dy) of the next cell and issues nothing: 34 instead of 64 atomics per channel and 16 x 1 tile
+// (the flush is bound by the memory-side atomic units whenever many workgroups flush a small grid at the same time).
+__device__ __forceinline__ void preadd_x16(f32x4 (&dxacc)[4], uint32_t off0, int ln) {
+    const int n16 = ln & 15, g = ln >> 4;
+    const bool recv = g < 2;
+    const bool inb = recv ? n16 >= 1 : n16 <= 14;
+    const int partner = inb ? (recv ? ln + 31 : ln - 31) : ln;
+    const uint32_t poff = (uint32_t)__shfl((int)off0, partner);
+    const bool pair = inb && (recv ? off0 == poff + 1u : poff == off0 + 1u);
+#pragma unroll
+    for (int c = 0; c < kC; ++c) {
+        const float pv = __shfl(dxacc[c >> 2][c & 3], partner);
+        dxacc[c >> 2][c & 3] = pair ? (recv ? dxacc[c >> 2][c & 3] + pv : 0.f) : dxacc[c >> 2][c & 3];
+    }
+}
+// .. and along y, across the NW waves of the workgroup: consecutive waves hold consecutive macro-tiles, i.e. rows y, y + 1, .. of the same
+// 16 columns, and the dy = 1 corners of wave w are the dy = 0 corners of wave w + 1 whenever the cell offsets differ by one grid row.  Sums
+// and offsets go through the wave regions of the LDS (`region` floats per wave, free between the last barrier of a unit and the first
+// store of the next); two workgroup barriers, executed by every wave.
+template <int NW, class Barrier>
+__device__ __forceinline__ void preadd_y16(f32x4 (&dxacc)[4], uint32_t off0, uint32_t row, int ln, int wave, lds_f* reg0, int region, Barrier&& barrier) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    const int g = ln >> 4;
+    lds_f* const mine = opaque(reg0 + wave * region + ln);
+    const bool up = (g & 1) != 0;                                  // dy = 1 quarters hand over, dy = 0 quarters receive
+    ((lds_u32_t*)mine)[12 * 64] = off0;
+    if (up) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
+    }
+    barrier();
+    const int pw = up ? wave + 1 : wave - 1;
+    const bool inw = pw >= 0 && pw < NW;
+    lds_cf* const theirs = opaque(reg0 + (inw ? pw : wave) * region + (up ? ln - 16 : ln + 16));
+    const uint32_t poff = ((const lds_u32_t*)theirs)[12 * 64];
+    const bool pair = inw && (up ? poff == off0 + row : off0 == poff + row);
+    if (!up) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float pv = theirs[i * 64];
+            dxacc[i >> 2][i & 3] += pair ? pv : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] = pair ? 0.f : dxacc[i >> 2][i & 3];
+    }
+    barrier();
+}
+
 // Barrier among the four waves of one HALF of the workgroup (waves 4 kh .. 4 kh + 3).  The two halves never read each other's images
 // (a wave contracts its weight-gradient tiles over the samples of its own half), so the only thing a workgroup-wide s_barrier adds is
 // lockstep: all eight waves in the same phase at the same time, both waves of a SIMD wanting the same pipe.  With one monotonic LDS
@@ -852,56 +903,10 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #ifdef NIC_T16_NOFLUSH
             flush = false;                                                  // timing ablation only
 #endif
-            if (flush && NIC_T16_PREADD) {
-                // neighbour pre-add along x: the dx = 1 corner of cell n - 1 IS the dx = 0 corner of cell n whenever their cell offsets
-                // differ by one element (same row of the grid, no clamping in between), so the lane of quarter (1, dy) hands its 12 sums
-                // to the lane of quarter (0, dy) of the next cell and issues nothing: 34 instead of 64 atomics per channel and 16 x 1 tile
-                // (the flush is bound by the memory-side atomic units whenever many workgroups flush a small grid at the same time)
-                const int n16 = ln & 15;
-                const bool recv = g < 2;
-                const bool inb = recv ? n16 >= 1 : n16 <= 14;
-                const int partner = inb ? (recv ? ln + 31 : ln - 31) : ln;
-                const uint32_t poff = (uint32_t)__shfl((int)blk_off0, partner);
-                const bool pair = inb && (recv ? blk_off0 == poff + 1u : poff == blk_off0 + 1u);
-#pragma unroll
-                for (int c = 0; c < kC; ++c) {
-                    const float pv = __shfl(dxacc[c >> 2][c & 3], partner);
-                    dxacc[c >> 2][c & 3] = pair ? (recv ? dxacc[c >> 2][c & 3] + pv : 0.f) : dxacc[c >> 2][c & 3];
-                }
-            }
+            if (flush && NIC_T16_PREADD) preadd_x16(dxacc, blk_off0, ln);
             if (NIC_T16_PREADD >= 2 && rg == 0) {                           // segment-uniform
-                // neighbour pre-add along y, across the waves of the workgroup: consecutive waves hold consecutive macro-tiles, i.e.
-                // rows y, y + 1, .. of the same 16 columns, and the dy = 1 corners of wave w are the dy = 0 corners of wave w + 1 whenever
-                // the cell offsets differ by one grid row.  Sums and offsets go through the wave regions of the LDS (free between the
-                // last barrier of a unit and the first store of the next): 17 x 9 instead of 8 x 34 atomics per channel and workgroup.
-                lds_f* const reg0 = (lds_f*)img0;
-                constexpr int REGION = S::SPW / 2;
-                static_assert(13 * 64 <= REGION, "pre-add scratch");
-                lds_f* const mine = opaque(reg0 + wave * REGION + ln);
-                const bool up = (g & 1) != 0;                                  // dy = 1 quarters hand over, dy = 0 quarters receive
-                ((lds_u32*)mine)[12 * 64] = blk_off0;
-                if (up) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
-                }
-                half_barrier(bar_cnt, bar_target, lane);
-                const int pw = up ? wave + 1 : wave - 1;
-                const bool inw = pw >= 0 && pw < 8;
-                lds_cf* const theirs = opaque(reg0 + (inw ? pw : wave) * REGION + (up ? ln - 16 : ln + 16));
-                const uint32_t poff = ((const lds_u32*)theirs)[12 * 64];
-                const uint32_t row = (uint32_t)p.g0.nx;
-                const bool pair = inw && (up ? poff == blk_off0 + row : blk_off0 == poff + row);
-                if (!up) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        const float pv = theirs[i * 64];
-                        dxacc[i >> 2][i & 3] += pair ? pv : 0.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) dxacc[i >> 2][i & 3] = pair ? 0.f : dxacc[i >> 2][i & 3];
-                }
-                half_barrier(bar_cnt, bar_target, lane);
+                static_assert(13 * 64 <= S::SPW / 2, "pre-add scratch");
+                preadd_y16<8>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, S::SPW / 2, [&]() { half_barrier(bar_cnt, bar_target, lane); });
             }
             if (flush) {
                 // one predicate per lane and grid instead of one per value: a lane whose 12 sums are all exact zeros (cell outside the
