@@ -119,11 +119,6 @@ typedef struct nic_path_desc {
  * nic_fused_forward, nic_fused_forward_backward, _img, nic_fused_backward_dy. */
 #define NIC_FLAG_GRID_BF16 16
 #define NIC_FLAG_GRID_FP16 32
-/* nic_fused_forward_backward / _img: `origins` points to HOST memory (num_crops * dim <= NIC_MAX_HOST_ORIGINS int32 values, read during the
- * call): the origins travel in the kernel arguments - no device buffer, no copy per step (a training loop that draws its crops on the
- * host, image_compression.py:26-50). */
-#define NIC_FLAG_ORIGINS_HOST 64
-#define NIC_MAX_HOST_ORIGINS 192
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
  * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three

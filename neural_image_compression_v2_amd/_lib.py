@@ -25,8 +25,6 @@ NIC_FLAG_SPLIT_TILE32 = 4
 NIC_FLAG_MLPN = 8
 NIC_FLAG_GRID_BF16 = 16
 NIC_FLAG_GRID_FP16 = 32
-NIC_FLAG_ORIGINS_HOST = 64
-NIC_MAX_HOST_ORIGINS = 192
 NIC_MAX_LINEAR = 5
 
 

@@ -72,7 +72,6 @@ int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->num_crops < 1) return NIC_E_SHAPE;
     if (d->max_workgroups < 0) return NIC_E_ARG;
     if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
-    if (!training && (d->flags & NIC_FLAG_ORIGINS_HOST)) return NIC_E_UNSUPPORTED;  // host origins: the fused training entry points only
     for (int a = 0; a < d->dim; ++a)
         if (d->extent[a] < 1 || d->g0_nodes[a] < 2 || d->g1_nodes[a] < 2) return NIC_E_SHAPE;
     // the kernels address a grid element as (wave-uniform channel-plane base) + (32-bit byte offset of the lane): a G0 channel
@@ -291,12 +290,6 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout));
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise, !mlpn && !t16);
-    if (d->flags & NIC_FLAG_ORIGINS_HOST) {                           // the origins travel in the kernel arguments
-        const int n_org = d->num_crops * d->dim;
-        if (n_org > NIC_MAX_HOST_ORIGINS) return NIC_E_UNSUPPORTED;
-        for (int i = 0; i < n_org; ++i) p.org_inline[i] = origins[i];
-        p.origins = nullptr;
-    }
     fill_mlp(p, mlp);
     p.g0_grad = g0_grad; p.g1_grad = g1_grad;
     p.target = target; p.dy = dy; p.y = y;

@@ -71,8 +71,7 @@ struct FusedParams {
     GridView g0, g1;
     float* g0_grad;
     float* g1_grad;
-    const int32_t* origins;            // device memory, or null: the origins are org_inline (NIC_FLAG_ORIGINS_HOST), read through kernel_origin()
-    int32_t org_inline[NIC_MAX_HOST_ORIGINS];
+    const int32_t* origins;
     const float* W[NIC_MAX_LINEAR];
     const float* b[NIC_MAX_LINEAR];
     int n_linear;
@@ -129,16 +128,6 @@ __device__ __forceinline__ void stage_all(int tid, Load&& ld, Store&& st) {
         const int idx = tid + NT * i;
         if (N % NT == 0 || idx < N) st(idx, v[i]);
     }
-}
-
-// origin `i` (= crop * dim + axis) of a launch: from the device buffer, or from the copy that travels in the kernel arguments (the kernel's
-// only argument is the FusedParams struct: a scalar load from the kernel-argument segment at a wave-uniform offset)
-__device__ __forceinline__ int kernel_origin(const FusedParams& p, int i) {
-    if (p.origins != nullptr) return p.origins[i];
-    typedef const int32_t __attribute__((address_space(4))) karg_i32;
-    typedef const char __attribute__((address_space(4))) karg_ch;
-    const karg_i32* ko = (const karg_i32*)((karg_ch*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(FusedParams, org_inline));
-    return ko[i];
 }
 
 template <class L>
@@ -996,7 +985,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             const int lc[3] = {p.pk_nc > 0 ? pk_lc[0] : pl & ((1 << lw) - 1), p.pk_nc > 0 ? pk_lc[1] : pl >> lw, p.pk_nc > 0 ? pk_lc[2] : 0};
 #pragma unroll
             for (int a = 0; a < L::DIM; ++a) {
-                org[a] = kernel_origin(p, crop * L::DIM + a);
+                org[a] = p.origins[crop * L::DIM + a];
                 blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
         }

@@ -477,8 +477,6 @@ class StepPlan:
         self.gm = [views[1 + i].view(self.params[i].shape) for i in range(2 * nl)]
         self.gg0, self.gg1 = views[1 + 2 * nl].view(self.g0.shape), views[2 + 2 * nl].view(self.g1.shape)
         self.d = geo.to_desc(self.g0, self.g1, False)
-        self.flags0 = int(self.d.flags)
-        self.org_host = (ctypes.c_int32 * (geo.num_crops * geo.dim))()
         self.m = _mlp_struct(self.params)
         self.gs = _grads_struct(self.gm)
         self.timg = target.to_struct(geo, [[0] * geo.dim] * geo.num_crops)
@@ -502,7 +500,6 @@ class StepPlan:
 
     def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int) -> StepOutput:
         geo, dev = self.geo, self.dev
-        host_org, org, org_ptr = False, None, None
         with torch.cuda.device(dev):
             if isinstance(coord, torch.Tensor) and coord.is_cuda:
                 org = coord.reshape(-1).to(torch.int32)
@@ -517,20 +514,10 @@ class StepPlan:
                     col = [r[a] for r in rows]
                     if min(col) < 0 or max(col) > self.hi[a]:
                         raise IndexError(f"axis {a}: crop origin {min(col)}..{max(col)} outside [0, {self.hi[a]}] (image / grid bounds)")
-                if self.n_org <= _lib.NIC_MAX_HOST_ORIGINS:
-                    # the origins travel in the kernel arguments (NIC_FLAG_ORIGINS_HOST): no device buffer, no copy kernel
-                    flat_rows = [v for r in rows for v in r]
-                    self.org_host[:] = flat_rows
-                    org_ptr = ctypes.addressof(self.org_host)
-                    host_org = True
-                else:
-                    org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
+                org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
             slot = self.steps % self.LOSS_SLOTS
             self.steps += 1
             d = self.d
-            d.flags = (self.flags0 | _lib.NIC_FLAG_ORIGINS_HOST) if host_org else self.flags0
-            if not host_org:
-                org_ptr = _lib.ptr(org)
             d.noise_mode = int(noise_mode)
             d.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
             d.noise_offset = int(noise_offset) & 0xFFFFFFFFFFFFFFFF
@@ -539,7 +526,7 @@ class StepPlan:
             self.clean = False               # set again by whoever zeroes the grid gradients (FusedAdam.zero_grad_in_step: in its own launch)
             ws = _lib.workspace(dev, int(self.lib.nic_workspace_bytes(ctypes.byref(d))))
             _lib.check(self.lib.nic_fused_forward_backward_img(
-                ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), org_ptr, ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
+                ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
                 self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
                 "nic_fused_forward_backward_img")
         return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)
