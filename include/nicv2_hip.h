@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 5
+#define NIC_ABI_VERSION 6
 
 enum {
     NIC_OK = 0,
@@ -115,10 +115,17 @@ typedef struct nic_path_desc {
 /* 16-bit grid STORAGE (the reference's FP_NUM_DTYPE = 16 maps its grids to torch.float16, utils.py:301-313; its own 16-bit run does not
  * train, readme.md:9): g0 / g1 point at bfloat16 or IEEE half arrays of the usual [C, Y, X] shape; every value is widened to fp32 in the
  * gather and all arithmetic, the gradients (dense fp32 tensors of the grids' shapes) and the optimiser state stay fp32 - nic_adam_multi
- * keeps an fp32 master and writes the 16-bit mirror (nic_adam_tensor.param16).  2D, NIC_FLAG_SPLIT_BF16 required:
- * nic_fused_forward, nic_fused_forward_backward, _img, nic_fused_backward_dy. */
+ * keeps an fp32 master and writes the 16-bit mirror (nic_adam_tensor.param16).  2D with NIC_FLAG_SPLIT_BF16 (nic_fused_forward,
+ * nic_fused_forward_backward, _img, nic_fused_backward_dy), or any layout with NIC_FLAG_BF16 (the training entry points). */
 #define NIC_FLAG_GRID_BF16 16
 #define NIC_FLAG_GRID_FP16 32
+/* PLAIN bf16 matrix products (BASELINE.json's "bf16"): every product operand - weights, noisy inputs, GELU outputs,
+ * the dZ of every layer, the stored GELU derivatives - is ONE bf16 value, accumulation / biases / activations / loss / grid-gradient
+ * sums are fp32 (csrc/fused_q16.hpp lists the rounding points; oracle/nic_oracle.py::mlp_forward_backward_bf16 restates them).
+ * Training entry points (nic_fused_forward_backward, _img, nic_fused_backward_dy), every layout (2D, 3D methods 3 and 4),
+ * n_linear 3 or 5, fp32 or 16-bit grid storage; 8 waves x 16 samples, two waves per SIMD.  Takes precedence over NIC_FLAG_SPLIT_BF16.
+ * Results are checked against the precision-emulating oracle at 1e-3 (outputs) and stay within ~1e-2 of the fp32 arithmetic. */
+#define NIC_FLAG_BF16 64
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
  * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three

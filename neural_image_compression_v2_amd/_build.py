@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnicv2_hip.so")
-SOURCES = ["simple_kernels.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip", "fused_t16.hip", "fused_mlpn.hip"]
-HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
+SOURCES = ["simple_kernels.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip", "fused_t16.hip", "fused_mlpn.hip", "fused_q1.hip", "fused_q2.hip", "fused_q3.hip", "fused_q4.hip"]
+HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", "fused_q16.hpp", "fused_q16_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results that vector instructions consume may live in the architectural VGPRs instead of bouncing
 # through v_accvgpr_read / write (split training kernel: 656 -> 423 of them, -0.7 %; fp32 2D 18 -> 0 spills; 3D 170 -> 115 / 135 -> 85)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-mfma-vgpr-form",

@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 5
+NIC_ABI_VERSION = 6
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -25,6 +25,7 @@ NIC_FLAG_SPLIT_TILE32 = 4
 NIC_FLAG_MLPN = 8
 NIC_FLAG_GRID_BF16 = 16
 NIC_FLAG_GRID_FP16 = 32
+NIC_FLAG_BF16 = 64
 NIC_MAX_LINEAR = 5
 
 

@@ -217,8 +217,9 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.pk_nc = 0;
     {
         const int bz = d->dim == 3 ? blocks(ez) : 1;
-        const int64_t nc = (int64_t)bx * by * bz, pt = (nc + 31) / 32;
-        if (allow_packed && fi.tx * fi.ty * fi.tz == 32 && nc < ((int64_t)1 << 24) && pt * 115 <= p.tiles_per_crop * 100) {
+        const int tsz = fi.tx * fi.ty * fi.tz;                                   // 32 blocks (fused_kernel) or 16 (fused_q16_kernel)
+        const int64_t nc = (int64_t)bx * by * bz, pt = (nc + tsz - 1) / tsz;
+        if (allow_packed && (tsz == 32 || tsz == 16) && nc < ((int64_t)1 << 24) && pt * 115 <= p.tiles_per_crop * 100) {
             p.pk_bx = bx; p.pk_by = by; p.pk_nc = (int)nc;
             p.edge_lw = -1;
             p.tiles_main = pt;
@@ -260,6 +261,32 @@ int use_mlpn(int layout, const nic_path_desc* d, const nic_mlp* m, bool grid_u8,
     return NIC_OK;
 }
 FusedInfo info_mlpn(int n_linear) { return FusedInfo{0, mlpn_record_floats(n_linear), 16, 1, 1, 73, 4}; }
+// plain-bf16 kernels (fused_q16.hpp): every layout, 3 or 5 Linear layers
+int q16_rec(int layout, int n_linear) {
+    switch (layout) {
+        case 1: return q16_record_floats<1>(n_linear);
+        case 2: return q16_record_floats<2>(n_linear);
+        case 3: return q16_record_floats<3>(n_linear);
+        default: return q16_record_floats<4>(n_linear);
+    }
+}
+FusedInfo info_q16(int layout, int n_linear) { return FusedInfo{0, q16_rec(layout, n_linear), 16, 1, 1, layout <= 2 ? 73 : (layout == 3 ? 127 : 79), 8}; }
+int launch_q16_any(int layout, int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s) {
+    switch (layout) {
+        case 1: return launch_q16<1>(n_linear, mode, p, grid, s);
+        case 2: return launch_q16<2>(n_linear, mode, p, grid, s);
+        case 3: return launch_q16<3>(n_linear, mode, p, grid, s);
+        default: return launch_q16<4>(n_linear, mode, p, grid, s);
+    }
+}
+int reduce_q16_any(int layout, int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+    switch (layout) {
+        case 1: return reduce_q16<1>(n_linear, partials, n_rec, g, loss, loss_scale, s);
+        case 2: return reduce_q16<2>(n_linear, partials, n_rec, g, loss, loss_scale, s);
+        case 3: return reduce_q16<3>(n_linear, partials, n_rec, g, loss, loss_scale, s);
+        default: return reduce_q16<4>(n_linear, partials, n_rec, g, loss, loss_scale, s);
+    }
+}
 FusedParams zero_params() {
     FusedParams p;
     ::memset(static_cast<void*>(&p), 0, sizeof(p));
@@ -283,13 +310,17 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         if (img->is_u8 && !(img->den > 0.f)) return NIC_E_ARG;
     }
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
+    const bool q16 = (d->flags & NIC_FLAG_BF16) != 0;                  // plain-bf16 products: every layout on the quarter kernels
+    if (q16 && (d->flags & NIC_FLAG_GRID_BF16) && (d->flags & NIC_FLAG_GRID_FP16)) return NIC_E_ARG;
     bool mlpn = false;
-    rc = use_mlpn(layout, d, mlp, false, mlpn);
-    if (rc) return rc;
-    const bool t16 = !mlpn && use_t16(layout, d);
-    const FusedInfo fi = mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout));
+    if (!q16) {
+        rc = use_mlpn(layout, d, mlp, false, mlpn);
+        if (rc) return rc;
+    }
+    const bool t16 = !q16 && !mlpn && use_t16(layout, d);
+    const FusedInfo fi = q16 ? info_q16(layout, mlp_depth(mlp)) : (mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout)));
     FusedParams p = zero_params();
-    fill_encode(p, d, fi, g0, g1, origins, noise, !mlpn && !t16);
+    fill_encode(p, d, fi, g0, g1, origins, noise, q16 || (!mlpn && !t16));
     fill_mlp(p, mlp);
     p.g0_grad = g0_grad; p.g1_grad = g1_grad;
     p.target = target; p.dy = dy; p.y = y;
@@ -308,13 +339,13 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_rcp = 1.0f / p.timg_den;
     }
     p.grid_kind = grid_kind_of(d);
-    if (p.grid_kind != 0 && !(mlpn || t16)) return NIC_E_UNSUPPORTED;
+    if (p.grid_kind != 0 && !(mlpn || t16 || q16)) return NIC_E_UNSUPPORTED;
     p.partials = (float*)workspace;
-    const int wpw = t16 ? 8 : 4;                              // waves per workgroup = work units per workgroup round
+    const int wpw = (t16 || q16) ? 8 : 4;                     // waves per workgroup = work units per workgroup round
     static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
     // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes: the reference's 3D sweep shape 0.368 -> 0.332 ms with
     //  method 4; method 3, twice the sums per lane, lost 5 % until its flush pre-added neighbouring sums and gains 6 % since)
-    balance_units(p, 1, wpw, t16 && two_seg, !t16 && !mlpn && two_seg, NIC_RG_SEG0);
+    balance_units(p, 1, wpw, (t16 || q16) && two_seg, !t16 && !q16 && !mlpn && two_seg, NIC_RG_SEG0);
     const int64_t units0 = p.seg_split << p.rg0_log2, units1 = (p.n_tiles - p.seg_split) << p.rg_log2;
     const int64_t units_max = units0 > units1 ? units0 : units1;
     if (units_max >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;                    // the kernels count work units in 32 bits
@@ -323,6 +354,11 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY);
+    if (q16) {
+        rc = launch_q16_any(layout, p.n_linear, mode, p, grid, s);
+        if (rc) return rc;
+        return reduce_q16_any(layout, p.n_linear, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
+    }
     if (mlpn) {
         rc = launch_mlpn(layout, p.n_linear, mode, p, grid, s);
         if (rc) return rc;
@@ -350,6 +386,8 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
     }
     if (train16_record_floats() > rec) rec = train16_record_floats();
     if (mlpn_record_floats(5) > rec) rec = mlpn_record_floats(5);
+    for (int l = 1; l <= 4; ++l)
+        if (q16_rec(l, 5) > rec) rec = q16_rec(l, 5);
     const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float) + (1u << 20);   // one record per workgroup, at most one workgroup per CU (+ 1 MiB: diagnostic builds)
     const size_t psnr = 1024 * sizeof(double);
     return fused > psnr ? fused : psnr;
@@ -373,11 +411,12 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     p.y = y;
     p.grid_kind = grid_kind_of(d);
     if (mlpn) {                                                       // one workgroup per CU (84 KB of weight images)
-        if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
         balance_units(p, 1, 4);
+        if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;     // the kernels count work units in 32 bits
         return launch_mlpn(layout, p.n_linear, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 1, 4, d->max_workgroups), (hipStream_t)stream);
     }
     balance_units(p, 2);
+    if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
     return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);
 }
 
@@ -401,6 +440,7 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     p.dq_rcp = 1.0f / p.dq_den;
     p.y = y; p.y_u8 = y_u8;
     balance_units(p, 2);
+    if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
     return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);
 }
 

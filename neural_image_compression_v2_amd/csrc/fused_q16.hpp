@@ -1,0 +1,1104 @@
+// fused_q16_kernel<Q, MODE, NL>: the fused training step in PLAIN bf16 products (NIC_FLAG_BF16) - one bf16 MFMA per product, fp32
+// accumulation - for every layout (2D, 3D method 3, 3D method 4) and decoder depth (NL = 3: the reference's ColorDecoder,
+// image_compression.py:57-64; NL = 5: the "4 x 64" decoder of BASELINE.json's north star), 8 waves x 16 samples = two waves per SIMD.
+//
+// What "plain bf16" rounds (restated in oracle/nic_oracle.py::mlp_forward_backward_bf16, the precision-emulating oracle):
+//   * every matrix-product operand is ONE bf16 value: the weights, the (noisy) input slots, the GELU outputs, the dZ of every layer;
+//     accumulation, biases (added in fp32, not carried on the constant-one slot), GELU, sigmoid, loss, db_out and the grid-gradient sums are fp32;
+//   * the GELU derivatives wait for the backward pass as bf16 (packed pairs: 8 registers per hidden layer instead of 16);
+//   * the encode (gathers, G1 blend, PE) and its backward are the fp32 arithmetic of every other kernel.
+// Against the split-bf16 kernels (fused_train16.hpp, fused_mlpn.hpp): a third of the matrix instructions, no hi / lo operand split
+// (~ 500 vector slots per round), half the LDS image traffic, and registers to spare - which is what lets the 5-layer decoder and
+// the 3D layouts run two waves per SIMD.
+//
+// Quarter layouts (QL<method>): lane l = 16 g + n is quarter g of sample n (a 16x16 accumulator tile gives it rows 4g .. 4g+3).  A quarter
+// owns NS input slots: G0 corner(s) - 12 channels each, ONE gather / atomic address per corner -, G1 channels 3g .. 3g+2 (blended over
+// the 4 / 8 corners), and a share of the positional-encoding rows, the LOD and the constant one.  Slots 8s .. 8s+7 of the four quarters
+// are the B operand of k-step s as they stand; a last half k-step (2D, method 4: slots 16 .. 19) is stored compactly.
+//   2D (Cin 73)        20 slots: G0 corner g | G1 3 | zero | PE rows 3g .. 3g+2 | LOD / one / zero            (fused_train16.hpp's layout)
+//   3D method 4 (79)   20 slots: tetrahedral corner g | G1 3 | PE rows 4g .. 4g+3 | PE row 16 / 17 / LOD / one
+//   3D method 3 (127)  32 slots: corners 2g, 2g+1 | G1 3 | PE rows 4g .. 4g+3 | PE row 16 / 17 / LOD / one
+// Hidden activations, weight images, [sample][position] wave images, transposed reads: the rules of fused_train16.hpp.
+//
+// LDS: bf16 weight images (W1 in slot order with a ZERO column at the constant-one slot - db1 still rides on it through the dW1
+// product), fp32 biases, and per wave: X | A_0 .. A_{NL-3} (the hidden activations, stored by the forward pass as the B fragments they
+// are, read again as the weight-gradient images) | DZ (two buffers where the LDS allows) | dZ_out.
+// Weight gradients: the backward pass is a sequence of PHASES - hidden layer NL-3, .., hidden layer 0, layer 1 - and the four 32x32 tiles
+// of phase j belong to the four waves of HALF j & 1 of the workgroup, each contracted over the samples of all eight waves (8 MFMAs
+// 32x32x16).  A wave therefore carries (NL - 1) / 2 accumulator tiles instead of NL - 1 (the 5-layer decoder fits two waves per SIMD),
+// and while the owners of a phase read the images the other half - their SIMD partners: waves w and w + 4 share a SIMD - is already in
+// the vector work of the next layer, storing its dZ into the OTHER DZ buffer: one barrier per phase plus one per round.
+#pragma once
+#include "fused_train16.hpp"
+
+namespace nic {
+
+// =====================================================================================================
+// quarter layouts
+// =====================================================================================================
+template <int METHOD>
+struct QL;
+
+struct QL2D {
+    static constexpr int DIM = 2, CIN = 73, K0 = 4, K1 = 4, NG0 = 1, NS = 20;
+    static constexpr bool TETRA = false;
+    static constexpr int LD1 = 80, LDX = 88;
+    __host__ __device__ static constexpr int slot_channel(int s, int g) { return slot16_channel(s, g); }
+    // in-kernel noise (oracle/nic_oracle.py::_kernel_noise_2d): quarter g consumes generator block g; field of slot s (-1: none)
+    static constexpr int NBLK = 1;
+    __host__ __device__ static constexpr int noise_blk(int) { return 0; }
+    __host__ __device__ static constexpr int noise_fld(int s) { return s < 15 ? s : (s == 15 ? -1 : s - 1); }
+};
+template <>
+struct QL<1> : QL2D {
+    static constexpr int PE = NIC_PE_TRIANGULAR;
+};
+template <>
+struct QL<2> : QL2D {
+    static constexpr int PE = NIC_PE_SINUSOIDAL;
+};
+// 3D: the 20 tail values (18 PE rows, LOD, the constant one) are dealt out five per quarter: PE rows 4g .. 4g+3, then row 16 / row 17 / LOD / one
+__host__ __device__ constexpr int tail3d_channel(int j, int g, int pe0) {      // pe0: first PE channel; LOD = pe0 + 18
+    if (j < 4) return pe0 + 4 * g + j;
+    return g == 0 ? pe0 + 16 : (g == 1 ? pe0 + 17 : (g == 2 ? pe0 + 18 : kSlotOne));
+}
+template <>
+struct QL<4> {                                                                  // tetrahedral G0 (fp_def.py:107-112, 187-223): Cin = 79
+    static constexpr int DIM = 3, CIN = 79, K0 = 4, K1 = 8, NG0 = 1, NS = 20;
+    static constexpr bool TETRA = true;
+    static constexpr int PE = NIC_PE_SINUSOIDAL;                                // fp_def.py:208
+    static constexpr int LD1 = 80, LDX = 88;
+    __host__ __device__ static constexpr int slot_channel(int s, int g) {
+        if (s < 12) return 12 * g + s;
+        if (s < 15) return 48 + 3 * g + (s - 12);
+        return tail3d_channel(s - 15, g, 60);
+    }
+    // in-kernel noise: quarter g consumes block g, field = slot (the constant one of quarter 3 takes none)
+    static constexpr int NBLK = 1;
+    __host__ __device__ static constexpr int noise_blk(int) { return 0; }
+    __host__ __device__ static constexpr int noise_fld(int s) { return s; }
+};
+template <>
+struct QL<3> {                                                                  // 8 raw G0 corners (fp_def.py:89-104, 148-184): Cin = 127
+    static constexpr int DIM = 3, CIN = 127, K0 = 8, K1 = 8, NG0 = 2, NS = 32;
+    static constexpr bool TETRA = false;
+    static constexpr int PE = NIC_PE_TRIANGULAR;                                // fp_def.py:169
+    static constexpr int LD1 = 144, LDX = 136;                                  // 288-byte weight rows: b128 row reads spread over the banks (ab/w16/banks.py model)
+    __host__ __device__ static constexpr int slot_channel(int s, int g) {
+        if (s < 24) return 24 * g + s;                                          // corner 2g + s / 12: dx = g >> 1, dy = g & 1, dz = s / 12
+        if (s < 27) return 96 + 3 * g + (s - 24);
+        return tail3d_channel(s - 27, g, 108);
+    }
+    // in-kernel noise: quarter g consumes blocks 2g (corner 2g, G1, tail: fields 0 .. 19) and 2g + 1 (corner 2g + 1: fields 0 .. 11)
+    static constexpr int NBLK = 2;
+    __host__ __device__ static constexpr int noise_blk(int s) { return (s >= 12 && s < 24) ? 1 : 0; }
+    __host__ __device__ static constexpr int noise_fld(int s) { return s < 12 ? s : (s < 24 ? s - 12 : s - 12); }
+};
+
+template <class Q>
+struct QInfo {
+    static constexpr int NG0V = 12 * Q::NG0;                   // raw G0 values / G0 gradient sums per lane
+    static constexpr int NG1V = 3 * Q::K1;                     // raw G1 values / G1 gradient sums per lane
+    static constexpr int NGS = NG0V + 3;                       // grid slots of a quarter (they come first)
+    static constexpr int KF = Q::NS / 8;                       // full k-steps of layer 1 (32 columns each)
+    static constexpr bool HALF = (Q::NS % 8) != 0;             // + a compact half k-step (4 slots per quarter, 16 columns)
+    static constexpr int KP = 4 * Q::NS;                       // columns of the X / W1 images
+    static constexpr int NDX = (NGS + 3) / 4;                  // dX tiles (4 slots each) that hold grid slots
+    static constexpr int NT1 = 2 * KF;                         // 32x32 tiles of dW1's full k-steps
+    static_assert(Q::NS % 4 == 0 && (NT1 == 4 || NT1 == 8), "layout");
+    // compact input column of (slot, quarter) and its inverse
+    __host__ __device__ static constexpr int rho(int s, int g) { return s < 8 * KF ? 32 * (s >> 3) + 8 * g + (s & 7) : 32 * KF + 4 * g + (s - 8 * KF); }
+    __host__ __device__ static constexpr int channel_of_rho(int r) {
+        if (r < 32 * KF) return Q::slot_channel(8 * (r >> 5) + (r & 7), (r >> 3) & 3);
+        return Q::slot_channel(8 * KF + (r & 3), (r - 32 * KF) >> 2);
+    }
+    __host__ __device__ static constexpr int rho_of_channel(int ch) {
+        for (int r = 0; r < KP; ++r)
+            if (channel_of_rho(r) == ch) return r;
+        return -1;
+    }
+};
+
+template <class Q, int NL>
+struct LdsQ {
+    using I = QInfo<Q>;
+    static constexpr int NH = NL - 2;                          // hidden 64 x 64 layers
+    static constexpr int LD1 = Q::LD1, LDH = 80, LDZ = 72, LDX = Q::LDX;
+    static constexpr int OFF_W1 = 0;                           // [64][LD1]
+    static constexpr int OFF_WH = OFF_W1 + kH * LD1;           // NH x [64][LDH], columns in position order
+    static constexpr int WSZ = kH * LDH;
+    static constexpr int OFF_WO = OFF_WH + NH * WSZ;           // [4][LDH], row 3 = zeros
+    static constexpr int OFF_B = OFF_WO + 4 * LDH;             // fp32: biases of layer 1 and the hidden layers [NH + 1][64] (natural order), output bias [4]
+    static constexpr int NBIAS = (NH + 1) * kH + 4;
+    static constexpr int OFF_IMG = (OFF_B + 2 * NBIAS + 7) & ~7;
+    // per wave (bf16 elements): X [16][LDX] | A_k [16][LDZ] x NH | DZ [16][LDZ] x DZB | dZ_out [4][16]
+    static constexpr int OFF_A = 16 * LDX, ASZ = 16 * LDZ, OFF_DZ = OFF_A + NH * ASZ;
+    static constexpr int SCRATCH = 2 * 64 * (I::NG0V + I::NG1V + 1);     // the head of the wave region doubles as fp32 scratch of the flush (group sums, pre-add)
+    static constexpr int spw_of(int dzb) { return (OFF_DZ + dzb * ASZ > SCRATCH ? OFF_DZ + dzb * ASZ : SCRATCH) + 64; }
+    static constexpr int DZB = (OFF_IMG + 8 * spw_of(2)) * 2 <= 163840 ? 2 : 1;      // two DZ buffers where they fit (not: method 3 with 5 layers)
+    static constexpr int OFF_D3 = spw_of(DZB) - 64;                                  // behind the scratch: its fourth row stays zero
+    static constexpr int SPW = OFF_D3 + 64;
+    static constexpr int TOTAL = OFF_IMG + 8 * SPW;
+    // phases of the backward pass: j = 0 .. NH - 1 = hidden layer NH - 1 - j, j = NH = layer 1.  Phase j belongs to half j & 1, accumulator slot j >> 1;
+    // with 8 dW1 tiles (method 3) every wave owns one of them: the half that does not own phase NH keeps it in an extra slot
+    static constexpr int NACC = (NH + 2) / 2 + (I::NT1 == 8 ? 1 : 0), XSLOT = (NH + 2) / 2;
+    static constexpr int TAIL_HALF = (NH + 1) & 1;                                   // HALF: the 16-column tail of dW1 goes to the half that idles in phase NH
+    __host__ __device__ static constexpr int dz_buf(int store) { return DZB == 2 ? (store & 1) : 0; }   // store 0: a_NH (forward), store 1 + j: the dZ of phase j
+    static_assert(TOTAL * 2 <= 163840, "LDS");
+    static_assert(OFF_WH % 8 == 0 && OFF_WO % 8 == 0 && OFF_B % 8 == 0 && OFF_A % 8 == 0 && ASZ % 8 == 0 && OFF_D3 % 8 == 0 && SPW % 8 == 0, "16-byte alignment");
+    // per-workgroup record of decoder-gradient sums (floats)
+    static constexpr int REC_W = 0;                            // 8 waves x NACC slots x 1024
+    static constexpr int REC_TAIL = 8 * NACC * 1024;           // 8 x 256 (HALF; the waves of TAIL_HALF write theirs): rows 16 (w & 3)..
+    static constexpr int REC_WAVE = REC_TAIL + (I::HALF ? 8 * 256 : 0);
+    static constexpr int WTAIL = NH * 64 + 192 + 4;            // db_hidden [NH][64] (position order), dW_out [3][64], db_out [3], loss
+    static constexpr int REC = REC_WAVE + 8 * WTAIL;
+};
+
+// 8 fp32 values -> one bf16 fragment (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 cvt8(const float (&x)[8]) {
+    u32x4 hp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        hp[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
+    return __builtin_bit_cast(bf16x8, hp);
+}
+__device__ __forceinline__ bf16x8 cvt_pair(const f32x4& a, const f32x4& b) {        // registers of row tiles 2s, 2s + 1 = k-step s
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return cvt8(x);
+}
+// the fp32 values of a packed fragment: elements 0..3 (lo = false) or 4..7 (lo = true)
+__device__ __forceinline__ f32x4 unpack4(const bf16x8& f, bool hi4) {
+    const u32x4 w = __builtin_bit_cast(u32x4, f);
+    const uint32_t a = hi4 ? w[2] : w[0], b = hi4 ? w[3] : w[1];
+    return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u), __builtin_bit_cast(float, b << 16),
+                 __builtin_bit_cast(float, b & 0xFFFF0000u)};
+}
+// acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
+template <int NT, bool ZERO = false, class LoadA>
+__device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, LoadA&& load_a) {
+    constexpr int PF = NIC_T16_PF < NT ? NIC_T16_PF : NT;
+    bf16x8 af[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) af[t] = load_a(t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = mfma16_bf(af[t % PF], bf, ZERO ? f32x4(0.f) : acc[t]);
+        if (t + PF < NT) af[t % PF] = load_a(t + PF);
+    }
+}
+
+template <class Q>
+struct CellRawQ {
+    float g0[QInfo<Q>::NG0V];      // [corner e of the quarter][channel]
+    float g1[QInfo<Q>::NG1V];      // [corner q][cc]
+};
+
+// corner offsets: G0 corner e of quarter g, G1 corner q
+template <class Q>
+__device__ __forceinline__ void q_g0_corner(int g, int e, int& dx, int& dy, int& dz) {
+    dx = g >> 1; dy = g & 1;
+    dz = Q::DIM == 2 ? 0 : (Q::TETRA ? (dx ^ dy) : e);         // fp_def.py:96-103 (bit 0 of the corner number = dz), :108-111
+}
+template <class Q>
+__device__ __forceinline__ void q_g1_corner(int q, int& dx, int& dy, int& dz) {
+    if (Q::DIM == 2) { dx = q >> 1; dy = q & 1; dz = 0; }
+    else { dx = (q >> 2) & 1; dy = (q >> 1) & 1; dz = q & 1; }
+}
+
+// 16-bit storage widened to fp32: both conversions, one select (kind is launch-uniform; no branch per element)
+__device__ __forceinline__ float widen16(uint32_t hbits, bool is_bf16) {
+    const float a = __builtin_bit_cast(float, hbits << 16);
+    const float b = (float)__builtin_bit_cast(_Float16, (uint16_t)hbits);
+    return is_bf16 ? a : b;
+}
+template <class Q, bool DO_G0, bool DO_G1>
+__device__ __forceinline__ void gather_cell_q(const FusedParams& p, uint32_t off0, uint32_t off1, int g, CellRawQ<Q>& raw) {
+    // ONE launch-uniform branch around the whole gather (a test per element serialised the loads of the in-round gathers: +30 % kernel time
+    // with 16-bit grids); 16-bit values are loaded as raw bits first and widened afterwards
+    const int kind = p.grid_kind;
+    uint32_t o0[Q::NG0], o1[Q::K1];                                       // element offsets of the corners (channel 0 / channel 3 g)
+#pragma unroll
+    for (int e = 0; e < (DO_G0 ? Q::NG0 : 0); ++e) {
+        int dx, dy, dz;
+        q_g0_corner<Q>(g, e, dx, dy, dz);
+        o0[e] = off0 + (uint32_t)p.g0.at(dx, dy, dz);
+    }
+#pragma unroll
+    for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
+        int dx, dy, dz;
+        q_g1_corner<Q>(q, dx, dy, dz);
+        o1[q] = off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+    }
+    const char* b0 = reinterpret_cast<const char*>(p.g0.p);
+    const char* b1 = reinterpret_cast<const char*>(p.g1.p);
+    if (kind == 0) {
+        const uint32_t pb0 = (uint32_t)p.g0.plane * 4u, pb1 = (uint32_t)p.g1.plane * 4u;
+#pragma unroll
+        for (int e = 0; e < (DO_G0 ? Q::NG0 : 0); ++e) {
+            uint32_t ob = o0[e] * 4u;
+#pragma unroll
+            for (int c = 0; c < kC; ++c, ob += pb0) raw.g0[e * kC + c] = *reinterpret_cast<const float*>(b0 + ob);
+        }
+#pragma unroll
+        for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
+            uint32_t ob = o1[q] * 4u;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc, ob += pb1) raw.g1[q * 3 + cc] = *reinterpret_cast<const float*>(b1 + ob);
+        }
+    } else {
+        const uint32_t pb0 = (uint32_t)p.g0.plane * 2u, pb1 = (uint32_t)p.g1.plane * 2u;
+        uint32_t h0[DO_G0 ? QInfo<Q>::NG0V : 1], h1[DO_G1 ? QInfo<Q>::NG1V : 1];
+#pragma unroll
+        for (int e = 0; e < (DO_G0 ? Q::NG0 : 0); ++e) {
+            uint32_t ob = o0[e] * 2u;
+#pragma unroll
+            for (int c = 0; c < kC; ++c, ob += pb0) h0[e * kC + c] = *reinterpret_cast<const uint16_t*>(b0 + ob);
+        }
+#pragma unroll
+        for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
+            uint32_t ob = o1[q] * 2u;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc, ob += pb1) h1[q * 3 + cc] = *reinterpret_cast<const uint16_t*>(b1 + ob);
+        }
+        const bool is_bf = kind == 1;
+#pragma unroll
+        for (int i = 0; i < (DO_G0 ? QInfo<Q>::NG0V : 0); ++i) raw.g0[i] = widen16(h0[i], is_bf);
+#pragma unroll
+        for (int i = 0; i < (DO_G1 ? QInfo<Q>::NG1V : 0); ++i) raw.g1[i] = widen16(h1[i], is_bf);
+    }
+}
+
+// the quarter's input slots for the sample at absolute coordinates q (xs indexed by slot; the fp32 arithmetic of every other kernel)
+template <class Q>
+__device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3], int g, float (&xs)[Q::NS], float (&kf)[3], const CellRawQ<Q>& raw) {
+    using I = QInfo<Q>;
+    constexpr int D = Q::DIM;
+    const nic_path_desc& d = p.d;
+    const int e = d.log2_step;
+    const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
+    Axis az;
+    if (D == 3) az = axis_coords(q[2], e);
+    else { az.i0 = az.i1 = 0; az.t1 = az.k1 = 0.f; }
+    kf[0] = ax.k1; kf[1] = ay.k1; kf[2] = az.k1;
+#pragma unroll
+    for (int c = 0; c < I::NG0V; ++c) xs[c] = raw.g0[c];
+    // ---- tail: PE rows, LOD, the constant one
+    if constexpr (D == 2) {
+        xs[15] = 0.f;
+        const float c = (g >> 1) ? ay.t1 : ax.t1;                       // rows 3 (g & 1) + i of dimension g >> 1 (utils.py:198-227)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = 3 * (g & 1) + i;
+            float v;
+            if (Q::PE == NIC_PE_TRIANGULAR) {
+                v = tri_pe_row(c, r, kP);
+            } else {
+                const int k = r >> 1;
+                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
+                float sv, cv;
+                sincos_cw(mul_rn(c, dv), sv, cv);
+                v = (r & 1) ? cv : sv;
+            }
+            xs[16 + i] = v;
+        }
+        xs[19] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
+    } else {
+        constexpr int T0 = I::NGS;                                      // first tail slot
+        if constexpr (Q::PE == NIC_PE_TRIANGULAR) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int R = j < 4 ? 4 * g + j : 16 + (g & 1);          // PE row 0 .. 17: dimension R / 6, row R % 6
+                const int dm = R >= 12 ? 2 : (R >= 6 ? 1 : 0);
+                const float c = dm == 0 ? ax.t1 : (dm == 1 ? ay.t1 : az.t1);
+                const float v = tri_pe_row(c, R - 6 * dm, kP);
+                xs[T0 + j] = j < 4 ? v : (g < 2 ? v : (g == 2 ? d.lod_value : 1.0f));
+            }
+        } else {
+            // rows 2 P, 2 P + 1 = (sin, cos) of pair P: dimension P / 3, frequency P % 3.  Quarter g: pairs 2g, 2g + 1, and pair 8 (rows 16, 17)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int P = u < 2 ? 2 * g + u : 8;
+                const int dm = P >= 6 ? 2 : (P >= 3 ? 1 : 0), k = P - 3 * dm;
+                const float c = dm == 0 ? ax.t1 : (dm == 1 ? ay.t1 : az.t1);
+                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
+                float sv, cv;
+                sincos_cw(mul_rn(c, dv), sv, cv);
+                if (u < 2) { xs[T0 + 2 * u] = sv; xs[T0 + 2 * u + 1] = cv; }
+                else xs[T0 + 4] = g == 0 ? sv : (g == 1 ? cv : (g == 2 ? d.lod_value : 1.0f));
+            }
+        }
+    }
+    // ---- G1 blend with the reference's factor order (fp_def.py:141-144, 176-183, 215-222)
+    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, kf[0], kf[1], kf[2]);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < Q::K1; ++c8) {
+            const uint32_t b = (gf.bits >> (3 * c8)) & 7u;
+            float v = raw.g1[c8 * 3 + cc];
+            v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+            v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+            if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
+            sum = c8 == 0 ? v : add_rn(sum, v);
+        }
+        xs[I::NG0V + cc] = sum;
+    }
+}
+
+// noise on every real channel (image_compression.py:250): caller-supplied tensor, or the in-kernel generator numbered by quarter
+template <class Q>
+__device__ __forceinline__ void add_noise_q(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int g, float (&xs)[Q::NS]) {
+    if (ns.mode == NIC_NOISE_NONE) return;
+    if (ns.mode == NIC_NOISE_TENSOR) {
+        const float* row = ns.tensor + n_local * Q::CIN;
+#pragma unroll
+        for (int s = 0; s < Q::NS; ++s) {
+            const int c0 = Q::slot_channel(s, 0), c1 = Q::slot_channel(s, 1), c2 = Q::slot_channel(s, 2), c3 = Q::slot_channel(s, 3);
+            if (c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0) continue;
+            const int ch = g == 0 ? c0 : (g == 1 ? c1 : (g == 2 ? c2 : c3));
+            xs[s] += ch >= 0 ? row[ch >= 0 ? ch : 0] : 0.f;
+        }
+        return;
+    }
+    U4 b[Q::NBLK];
+#pragma unroll
+    for (int i = 0; i < Q::NBLK; ++i) b[i] = noise_block(ns, sample_global, Q::NBLK * g + i);
+#pragma unroll
+    for (int s = 0; s < Q::NS; ++s) {
+        const int f = Q::noise_fld(s);
+        if (f < 0) continue;
+        const bool r0 = Q::slot_channel(s, 0) >= 0, r1 = Q::slot_channel(s, 1) >= 0, r2 = Q::slot_channel(s, 2) >= 0, r3 = Q::slot_channel(s, 3) >= 0;
+        if (!(r0 || r1 || r2 || r3)) continue;
+        const float v = noise_field(ns, b[Q::noise_blk(s)], f);
+        if (r0 && r1 && r2 && r3) xs[s] += v;
+        else xs[s] += (g == 0 ? r0 : (g == 1 ? r1 : (g == 2 ? r2 : r3))) ? v : 0.f;
+    }
+}
+
+// G1 sums of the lanes whose G0 cells share a G1 cell are added across lanes before the flush (one atomic per node and instruction):
+// partner = the lane whose block coordinate differs in the last bit along one axis, when it sits in the same 16-lane block list and
+// really has the same (clamped) G1 cell.  Regular tiles: 2^lw x 16 / 2^lw x 1 blocks; packed tiling: 16 consecutive blocks of the
+// crop's pk[0] x pk[1] x pk[2] list.
+template <class Q>
+__device__ __forceinline__ void combine_g1_lanes_q(float (&g1s)[QInfo<Q>::NG1V], uint32_t off1, const int (&blk)[3], int lane, int lw, bool packed,
+                                                   const int (&pk)[3], const int (&pk_lc)[3]) {
+    constexpr int D = Q::DIM;
+    const int T[3] = {packed ? pk[0] : 1 << lw, packed ? pk[1] : 16 >> lw, packed ? pk[2] : 1};
+    const int STR[3] = {1, packed ? pk[0] : 1 << lw, packed ? pk[0] * pk[1] : 16};
+    const int pl = lane & 15;
+    const int lc[3] = {packed ? pk_lc[0] : pl & (T[0] - 1), packed ? pk_lc[1] : pl >> lw, packed ? pk_lc[2] : 0};
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        const bool odd = blk[a] & 1;
+        const int pc = lc[a] + (odd ? -1 : 1);
+        const int ppl = pl + (odd ? -STR[a] : STR[a]);
+        const bool inb = pc >= 0 && pc < T[a] && ppl >= 0 && ppl < 16;
+        const int partner = inb ? lane + (odd ? -STR[a] : STR[a]) : lane;
+        const bool pair = inb && (uint32_t)__shfl((int)off1, partner) == off1;
+#pragma unroll
+        for (int i = 0; i < QInfo<Q>::NG1V; ++i) {
+            const float pv = __shfl(g1s[i], partner);
+            g1s[i] = pair ? (odd ? 0.f : g1s[i] + pv) : g1s[i];
+        }
+    }
+}
+
+// Neighbour pre-add of the G0 sums along x inside a wave (2D and method 3: quarter (dx = 1, dy) of cell n - 1 addresses the nodes of
+// quarter (dx = 0, dy) of cell n whenever their cell offsets differ by one element) - see preadd_x16; NT tiles of four sums per lane
+template <int NT, int NA>
+__device__ __forceinline__ void preadd_x_q(f32x4 (&dxacc)[NA], uint32_t off0, int ln) {
+    const int n16 = ln & 15, g = ln >> 4;
+    const bool recv = g < 2;
+    const bool inb = recv ? n16 >= 1 : n16 <= 14;
+    const int partner = inb ? (recv ? ln + 31 : ln - 31) : ln;
+    const uint32_t poff = (uint32_t)__shfl((int)off0, partner);
+    const bool pair = inb && (recv ? off0 == poff + 1u : poff == off0 + 1u);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = __shfl(dxacc[t][r], partner);
+            dxacc[t][r] = pair ? (recv ? dxacc[t][r] + pv : 0.f) : dxacc[t][r];
+        }
+}
+// .. and along y across the 8 waves (consecutive waves hold consecutive rows y of the same 16 columns): see preadd_y16
+template <int NT, int NA, class Barrier>
+__device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, uint32_t row, int ln, int wave, lds_f* reg0, int region, Barrier&& barrier) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    const int g = ln >> 4;
+    lds_f* const mine = opaque(reg0 + wave * region + ln);
+    const bool up = (g & 1) != 0;
+    ((lds_u32_t*)mine)[4 * NT * 64] = off0;
+    if (up) {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
+    }
+    barrier();
+    const int pw = up ? wave + 1 : wave - 1;
+    const bool inw = pw >= 0 && pw < 8;
+    lds_cf* const theirs = opaque(reg0 + (inw ? pw : wave) * region + (up ? ln - 16 : ln + 16));
+    const uint32_t poff = ((const lds_u32_t*)theirs)[4 * NT * 64];
+    const bool pair = inw && (up ? poff == off0 + row : off0 == poff + row);
+    if (!up) {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) {
+            const float pv = theirs[i * 64];
+            dxacc[i >> 2][i & 3] += pair ? pv : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) dxacc[i >> 2][i & 3] = pair ? 0.f : dxacc[i >> 2][i & 3];
+    }
+    barrier();
+}
+
+#ifndef NIC_Q16_PREADD
+#define NIC_Q16_PREADD 2
+#endif
+
+// =====================================================================================================
+template <class Q, int MODE, int NL>
+__global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
+    using S = LdsQ<Q, NL>;
+    using I = QInfo<Q>;
+    constexpr int NH = S::NH, D = Q::DIM, NS = Q::NS, KF = I::KF, NDX = I::NDX, NG0T = I::NG0V / 4;
+    constexpr bool HALF = I::HALF;
+    constexpr int LD1 = S::LD1, LDH = S::LDH, LDZ = S::LDZ, LDX = S::LDX;
+    static_assert(MODE != MODE_INFER && (NL == 3 || NL == 5), "training kernel, 3 or 5 Linear layers");
+    // raw grid values gathered once per macro-tile (every sample a lane handles there lies in the same G0 / G1 cell) where the register
+    // budget of two waves per SIMD allows, otherwise at the head of every round (L1 / L2 hits): NIC_Q16_HOIST bit 0: G0, bit 1: G1
+#ifdef NIC_Q16_HOIST
+    constexpr int HOIST = NIC_Q16_HOIST;
+#else
+    // measured (4K / 128^3 launches, interleaved A/B on one box, hoist 0 / 1 / 3): 2D NL 3: 1.51 / 1.49 / 1.45 ms, NL 5: 3.65 / 3.77 / 4.25 (spills);
+    // method 4: 0.616 / 0.558 / 0.543 ms; method 3: 0.525 / 0.539 / 0.601 (spills)
+    constexpr int HOIST = NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : 0;
+#endif
+    constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
+    __shared__ __attribute__((aligned(16))) __bf16 smemq[S::TOTAL];
+    lds_bf* const sm = (lds_bf*)smemq;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---------------- prologue: bf16 weight images, fp32 biases, wave regions zeroed
+    stage_all<kH * LD1, 512>(tid,
+        [&](int idx) {
+            const int o = idx / LD1, r = idx - o * LD1;
+            const int ch = r < I::KP ? I::channel_of_rho(r) : kSlotZero;
+            const float v = p.W[0][o * Q::CIN + (ch >= 0 ? ch : 0)];
+            return ch >= 0 ? v : 0.f;                                   // the constant-one column stays zero: b1 is added in fp32
+        },
+        [&](int idx, float v) { sm[S::OFF_W1 + idx] = (__bf16)v; });
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const float* Wk = p.W[1 + k];
+        stage_all<kH * LDH, 512>(tid,
+            [&](int idx) {
+                const int o = idx / LDH, ps = idx - o * LDH;
+                const float v = Wk[o * kH + hid16(ps < kH ? ps : 0)];
+                return ps < kH ? v : 0.f;
+            },
+            [&](int idx, float v) { sm[S::OFF_WH + k * S::WSZ + idx] = (__bf16)v; });
+    }
+    stage_all<4 * LDH, 512>(tid,
+        [&](int idx) {
+            const int c = idx / LDH, ps = idx - c * LDH;
+            return (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
+        },
+        [&](int idx, float v) { sm[S::OFF_WO + idx] = (__bf16)v; });
+    lds_f* const Bs = (lds_f*)(sm + S::OFF_B);
+    for (int idx = tid; idx < (NH + 1) * kH; idx += 512) Bs[idx] = p.b[idx / kH][idx % kH];
+    if (tid < 4) Bs[(NH + 1) * kH + tid] = tid < 3 ? p.b[NL - 1][tid] : 0.f;
+    for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
+    __syncthreads();
+
+    // ---------------- launch-lifetime accumulators: the weight-gradient tiles this wave owns
+    f32x16 accW[S::NACC];                // slot j >> 1: the tile (wave & 3) of the phases j this wave's half owns (LdsQ); XSLOT: its dW1 tile when there are 8
+    f32x4 accT = f32x4(0.f);             // HALF: dW1's last 16 columns, rows 16 (wave & 3).. (the waves of TAIL_HALF)
+    f32x4 accWOq = f32x4(0.f), accBH = f32x4(0.f);   // accBH: row k = db of hidden layer k (4x4x4 MFMAs against ones in row k only)
+#pragma unroll
+    for (int k = 0; k < S::NACC; ++k) accW[k] = f32x16(0.f);
+    float accBO[3] = {0.f, 0.f, 0.f}, accLoss = 0.f;
+    const int T4 = wave & 3, kh = wave >> 2;
+    const int to = T4 >> 1, tk = T4 & 1;
+    lds_bf* const img0 = sm + S::OFF_IMG;
+    auto barrier = [&]() { wg_lds_barrier(); };
+
+    // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave), two segments: fused_train16.hpp
+    const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int seg_tile0 = seg ? (int)p.seg_split : 0;
+    const int seg_tiles = seg ? (int)p.n_tiles - (int)p.seg_split : (int)p.seg_split;
+    const int rg = seg ? p.rg_log2 : 0;
+    if (seg_tiles <= 0) continue;                                       // launch-uniform
+    const int n_units = seg_tiles << rg;
+    const int chunk = (((n_units + 7) >> 3) + 7) & ~7;
+    const int t_begin = xcd * chunk;
+    const int t_end = t_begin + chunk < n_units ? t_begin + chunk : n_units;
+    const int lstride = nb8 * 8;
+    const int base0 = t_begin + (int)(blockIdx.x >> 3) * 8;
+    const int n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
+    const int tiles_per_crop = (int)p.tiles_per_crop, tiles_main = (int)p.tiles_main;
+    const int rounds_unit = (p.niter * p.passes) >> rg;
+    const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);
+    const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+    const bool packed = p.pk_nc > 0;                                    // launch-uniform
+    const int pk[3] = {p.pk_bx, p.pk_by, packed ? p.pk_nc / (p.pk_bx * p.pk_by) : 1};
+
+    for (int kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
+        const int base = base0 + (kk < n_my ? kk : 0) * lstride;
+        const bool tile_ok = base + wave < t_end;
+        const int unit = tile_ok ? base + wave : t_end - 1;
+        const int tile = seg_tile0 + (unit >> rg);
+        int it_len = rounds_unit, it_begin = (int)(unit & ((1 << rg) - 1)) * rounds_unit;
+        if (shift) {
+            if (kk == 0) { it_begin += shift; it_len -= shift; }
+            else if (kk == n_my) it_len = shift;
+        }
+        // ---------- macro-tile -> this lane's cell (absolute block coordinates) and crop
+        int lw = 4;
+        int org[3] = {0, 0, 0}, blk[3] = {0, 0, 0}, pk_lc[3] = {0, 0, 0};
+        const int crop = tile / tiles_per_crop;
+        float g1s[I::NG1V];                                                  // G1 gradient sums of the cell
+        f32x4 dxacc[NDX];                                                    // tiles 0 .. NG0T-1: the cell's G0 gradient sums (persistent over the rounds)
+        uint32_t blk_off0, blk_off1;
+        CellRawQ<Q> raw;
+        {
+            const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
+            int tt = tile - crop * tiles_per_crop;
+            int boff[3] = {0, 0, 0};
+            if (packed) {
+                // packed tiling: 16 consecutive blocks of the crop's block list (x fastest); numbers past the end land outside the crop
+                const int ci = tt * 16 + n16;
+                const int cy = ci / pk[0];
+                pk_lc[0] = ci - cy * pk[0];
+                pk_lc[2] = D == 3 ? cy / pk[1] : 0;
+                pk_lc[1] = D == 3 ? cy - pk_lc[2] * pk[1] : cy;
+            } else if (p.edge_lw < 0 || tt < tiles_main) {
+                boff[1] = tt % p.tiles_y;                 // regular tile: 16 x 1 x 1 cells; y fastest, then z, then the 16-cell column along x
+                tt /= p.tiles_y;
+                boff[2] = D == 3 ? tt % p.tiles_z : 0;
+                boff[0] = (D == 3 ? tt / p.tiles_z : tt) * 16;
+            } else {
+                int e = tt - tiles_main;                  // edge tile: 2^lw x (16 >> lw) x 1 cells
+                lw = p.edge_lw;
+                boff[2] = D == 3 ? e % p.tiles_z : 0;
+                if (D == 3) e /= p.tiles_z;
+                boff[1] = e * (16 >> lw);
+                boff[0] = p.full_x * 16;
+            }
+            const int lc[3] = {packed ? pk_lc[0] : n16 & ((1 << lw) - 1), packed ? pk_lc[1] : n16 >> lw, packed ? pk_lc[2] : 0};
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                org[a] = p.origins[crop * D + a];
+                blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
+            }
+#pragma unroll
+            for (int i = 0; i < I::NG1V; ++i) g1s[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NDX; ++t) dxacc[t] = f32x4(0.f);
+            const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};
+            cell_offsets<Q>(p, qb, blk_off0, blk_off1);
+            gather_cell_q<Q, HG0, HG1>(p, blk_off0, blk_off1, g, raw);
+        }
+
+        for (int it = it_begin; it < it_begin + it_len; ++it) {
+            // ================= forward =================
+            bf16x8 dpk[NH + 1][2];                                            // GELU derivatives of every hidden activation, bf16, packed like the B fragments
+            float dz3[3];
+            float kf[3];                                                      // G1 interpolation fractions of the sample
+            {
+                const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
+                if (!HG0 || !HG1) gather_cell_q<Q, !HG0, !HG1>(p, blk_off0, blk_off1, g, raw);
+                // ---------- which sample does this lane own in this round
+                bool valid = tile_ok;
+                int64_t n;
+                int q[3] = {0, 0, 0};
+                {
+                    const int m1 = (1 << p.lm) - 1;
+                    const int pass = it >> (p.lm * D), its = it & (p.niter - 1);
+                    int j[3];
+                    if (D == 2) { j[0] = its >> p.lm; j[1] = its & m1; j[2] = 0; }
+                    else { j[0] = its >> (2 * p.lm); j[1] = (its >> p.lm) & m1; j[2] = its & m1; }
+                    int idx[3] = {0, 0, 0};
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const int ext = p.d.extent[a];
+                        const int i = (blk[a] << p.lm) + j[a] - org[a];
+                        valid = valid && i >= 0 && i < ext;
+                        idx[a] = i < 0 ? 0 : (i >= ext ? ext - 1 : i);
+                        q[a] = org[a] + idx[a];
+                    }
+                    int64_t lin = (int64_t)idx[0] * p.d.extent[1] + idx[1];
+                    if (D == 3) lin = lin * p.d.extent[2] + idx[2];
+                    n = ((int64_t)crop * p.passes + pass) * p.n_per_crop + lin;
+                }
+                // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
+                float tgt[3] = {0.f, 0.f, 0.f};
+                if (MODE == MODE_TRAIN_IMG) {
+                    int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
+                    if (D == 3) off += (int64_t)q[2] * p.timg_s[2];
+                    uint32_t rgbx = 0u;
+                    if (p.timg_u8 == 2) rgbx = reinterpret_cast<const uint32_t*>(p.timg)[off];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (p.timg_u8) {
+                            const float u = p.timg_u8 == 2 ? (float)((rgbx >> (8 * c)) & 255u) : (float)(reinterpret_cast<const uint8_t*>(p.timg) + c * p.timg_cs)[off];
+                            const float t0 = mul_rn(u, p.timg_rcp);
+                            tgt[c] = fmaf(fmaf(-t0, p.timg_den, u), p.timg_rcp, t0);
+                        } else {
+                            tgt[c] = (reinterpret_cast<const float*>(p.timg) + c * p.timg_cs)[off];
+                        }
+                    }
+                } else {
+                    const float* tp = (MODE == MODE_TRAIN_MSE ? p.target : p.dy) + n * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) tgt[c] = tp[c];
+                }
+                // ---------- input slots
+                float xs[NS];
+                encode_q<Q>(p, q, g, xs, kf, raw);
+                add_noise_q<Q>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+                lds_bf* const imgw = img0 + wave * S::SPW;
+                lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));                       // 64-column weight images: row n16, columns 8 g ..
+                lds_cf* const b_row = opaque(Bs + 4 * g);
+                f32x4 z[4];
+                // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n] + b1[o]
+                {
+                    lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
+                    lds_bf* const x_st = opaque(imgw + n16 * LDX + 8 * g);                                // fragment stores: row n, columns 32 s + 8 g
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[16 * t]);
+#pragma unroll
+                    for (int s = 0; s < KF; ++s) {
+                        const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6], xs[8 * s + 7]};
+                        const bf16x8 bf = cvt8(xv);
+                        st_frag(&x_st[32 * s], bf);
+                        kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
+                    }
+                    if constexpr (HALF) {   // slots 8 KF .. 8 KF + 3: compact columns 32 KF + 4 g + j
+                        lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
+                        lds_bf* const x_st2 = opaque(imgw + n16 * LDX + 32 * KF + 4 * g);
+                        const float xv[8] = {xs[8 * KF], xs[8 * KF + 1], xs[8 * KF + 2], xs[8 * KF + 3], 0.f, 0.f, 0.f, 0.f};
+                        const bf16x8 bf = cvt8(xv);
+                        const s16x8 bh = __builtin_bit_cast(s16x8, bf);
+                        *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
+                        kstep_b<4>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                    }
+                }
+                // ---------- hidden layers: the B fragments of layer k + 1 are the image A_k of its weight gradient
+                bf16x8 af[2];
+                {
+                    f32x4 a4[4], d4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a4[t], d4[t]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { af[s] = cvt_pair(a4[2 * s], a4[2 * s + 1]); dpk[0][s] = cvt_pair(d4[2 * s], d4[2 * s + 1]); }
+                }
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    lds_bf* const a_st = opaque(imgw + S::OFF_A + k * S::ASZ + n16 * LDZ + 8 * g);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[(k + 1) * kH + 16 * t]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        st_frag(&a_st[32 * s], af[s]);
+                        kstep_b<4>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
+                    }
+                    f32x4 a4[4], d4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a4[t], d4[t]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { af[s] = cvt_pair(a4[2 * s], a4[2 * s + 1]); dpk[k + 1][s] = cvt_pair(d4[2 * s], d4[2 * s + 1]); }
+                }
+                // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); its input fragments are the
+                // image dW_out contracts with (the DZ region is free until the first dZ is stored)
+                float yv[3];
+                {
+                    lds_cbf* const wo_row = opaque((lds_cbf*)(sm + S::OFF_WO + (n16 < 3 ? n16 : 3) * LDH + 8 * g));
+                    lds_bf* const dz_st = opaque(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + n16 * LDZ + 8 * g);
+                    f32x4 z3;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        st_frag(&dz_st[32 * s], af[s]);
+                        z3 = mfma16_bf(ld_frag(&wo_row[32 * s]), af[s], s == 0 ? f32x4(0.f) : z3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[(NH + 1) * kH + c]);
+                }
+                const bool own = valid && g == 0;
+                if (p.y != nullptr && own) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+                }
+                // ---------- dZ_out
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float gr;
+                    if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
+                        const float diff = own ? yv[c] - tgt[c] : 0.f;
+                        accLoss += diff * diff;
+                        gr = p.grad_scale * diff;
+                    } else {
+                        gr = own ? tgt[c] : 0.f;
+                    }
+                    dz3[c] = gr * yv[c] * (1.0f - yv[c]);
+                    accBO[c] += dz3[c];
+                }
+                if (g == 0) {
+                    lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) d3_st[c * 16] = (__bf16)dz3[c];
+                }
+            }
+            wave_lds_fence();
+            // ================= backward =================
+            f32x4 dzc[4];                                                   // dZ of the pre-activation of the layer at hand; ends as layer 1's dZ
+            {
+                const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, g = ln >> 4;
+                lds_bf* const imgw = img0 + wave * S::SPW;
+                lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                {   // dW_out[c][pos = lane] += sum_n dZ_out[c][n] a_last[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
+                    lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (ln & 3) * 16));
+                    s16x4 bh[4], ah[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        bh[r] = tr4(&dz_b44[r * LDZ]);
+                        ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accWOq = mfma4_bf(ah[r], bh[r], accWOq);
+                }
+                {   // dA_last = W_out^T dZ_out (k = c: quarter 0 carries dZ_out in elements 0..2), dZ = dA * gelu'
+                    lds_cbf* const wo_tr = opaque((lds_cbf*)(sm + S::OFF_WO + q4 * LDH + 8 * p4));
+                    const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const bf16x8 bf = cvt8(dzv);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const s16x4 a = tr4(&wo_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
+                        dzc[t] = mfma16_bf(join8(a, a), bf, f32x4(0.f)) * unpack4(dpk[NH][t >> 1], t & 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = NH - 1; k >= 0; --k) {
+                // phase j: hidden layer k: a_k -> z -> a_{k+1};  dzc = dZ of z
+                const int j = NH - 1 - k;
+                const int DZO = S::OFF_DZ + S::dz_buf(1 + j) * S::ASZ;
+                f32x4 acc[4];
+                {
+                    const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
+                    lds_bf* const imgw = img0 + wave * S::SPW;
+                    if (S::DZB == 1) wave_lds_fence();                         // one buffer: this wave's dW_out / db reads of it are issued before it is overwritten
+                    lds_cbf* const wh_tr = opaque((lds_cbf*)(sm + S::OFF_WH + k * S::WSZ + (4 * g + q4) * LDH + 8 * p4));
+                    lds_bf* const dz_st = opaque(imgw + DZO + n16 * LDZ + 8 * g);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
+                        st_frag(&dz_st[32 * s], bf);
+                        auto la = [&](int t) {
+                            const int co = 32 * (t >> 1) + 4 * (t & 1);
+                            return join8(tr4(&wh_tr[32 * s * LDH + co]), tr4(&wh_tr[(32 * s + 16) * LDH + co]));
+                        };
+                        if (s == 0) kstep_b<4, true>(acc, bf, la);
+                        else kstep_b<4>(acc, bf, la);
+                    }
+                    wave_lds_fence();
+                    {   // db[pos = lane] += sum_n dZ[pos][n]: 4x4x4 MFMAs against a block of ones
+                        lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + DZO + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                        const short one = (ln & 3) == k ? (short)0x3F80 : (short)0;      // A[i][.] = 1 for output row i = k only
+                        const s16x4 ones = {one, one, one, one};
+                        s16x4 bh[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bh[r] = tr4(&dz_b44[r * LDZ]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accBH = mfma4_bf(ones, bh[r], accBH);
+                    }
+                }
+                barrier();                                                     // every wave's dZ image of this phase is in place
+                if (kh == (j & 1)) {   // dW_hidden[k] tile (to, tk) += sum over the samples of all eight waves of dZ[o][n] a_k[i][n]
+                    const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
+                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZO + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+                    lds_cbf* const a_t32 = opaque((lds_cbf*)(img0 + S::OFF_A + k * S::ASZ + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                        const bf16x8 b = join8(tr4(&a_t32[v * S::SPW]), tr4(&a_t32[v * S::SPW + LDZ]));
+                        accW[j >> 1] = mfma_bf(a, b, accW[j >> 1]);
+                    }
+                }
+                if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+            }
+            // ---------- phase NH, layer 1: dX = W1^T dZ1 for the grid slots (tile t = slots 4t .. 4t+3); tiles 0 .. NG0T-1 (the G0 channels) keep
+            // their running sums over the rounds in the product's C operand; the dZ1 fragments are the dZ1 image of dW1
+            constexpr int DZ1 = S::OFF_DZ + S::dz_buf(1 + NH) * S::ASZ;
+            {
+                const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
+                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
+                lds_bf* const dz_st = opaque(img0 + wave * S::SPW + DZ1 + n16 * LDZ + 8 * g);
+                if (S::DZB == 1) wave_lds_fence();
+#pragma unroll
+                for (int t = NG0T; t < NDX; ++t) dxacc[t] = f32x4(0.f);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
+                    st_frag(&dz_st[32 * s], bf);
+                    kstep_b<NDX>(dxacc, bf, [&](int t) {
+                        const int co = 32 * (t >> 1) + 4 * (t & 1);
+                        return join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
+                    });
+                }
+                // G1 slots: I::NG0V .. + 2 = registers 0 .. 2 of tile NG0T
+                const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, kf[0], kf[1], kf[2]);
+#pragma unroll
+                for (int c8 = 0; c8 < Q::K1; ++c8) {
+                    const float w = g1_corner_factor<D>(gf, c8);
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) g1s[c8 * 3 + cc] = fmaf(dxacc[NG0T][cc], w, g1s[c8 * 3 + cc]);
+                }
+            }
+            barrier();
+            {
+                const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
+                if constexpr (I::NT1 == 4) {
+                    if (kh == (NH & 1)) {
+                        // dW1, the 64 columns of the full k-steps: tile (to, tk) over all eight source waves
+                        lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+                        lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                            const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
+                            accW[NH >> 1] = mfma_bf(a, b, accW[NH >> 1]);
+                        }
+                    }
+                } else {
+                    // 128 columns: every wave owns one of the 8 tiles - (row half wave >> 2, column block wave & 3) - over all eight source waves
+                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * kh + 16 * cg + 4 * p4));
+                    lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * T4 + 16 * cg + 4 * p4));
+                    f32x16 c = kh == (NH & 1) ? accW[NH >> 1] : accW[S::XSLOT];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                        const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
+                        c = mfma_bf(a, b, c);
+                    }
+                    if (kh == (NH & 1)) accW[NH >> 1] = c;
+                    else accW[S::XSLOT] = c;
+                }
+                if constexpr (HALF) {
+                    if (kh == S::TAIL_HALF) {
+                        // the last 16 columns as a 16x16 tile (rows 16 T4 ..): four k-steps of 32 samples; quarter G reads source wave
+                        // 2 uu + (G >> 1), samples 4 q' + 2 (G & 1) + rd
+                        lds_cbf* const dz_t16 = opaque((lds_cbf*)(img0 + (g >> 1) * S::SPW + DZ1 + (4 * q4 + 2 * (g & 1)) * LDZ + 16 * T4 + 4 * p4));
+                        lds_cbf* const x_t16 = opaque((lds_cbf*)(img0 + (g >> 1) * S::SPW + (4 * q4 + 2 * (g & 1)) * LDX + 32 * KF + 4 * p4));
+#pragma unroll
+                        for (int uu = 0; uu < 4; ++uu) {
+                            const bf16x8 a = join8(tr4(&dz_t16[2 * uu * S::SPW]), tr4(&dz_t16[2 * uu * S::SPW + LDZ]));
+                            const bf16x8 b = join8(tr4(&x_t16[2 * uu * S::SPW]), tr4(&x_t16[2 * uu * S::SPW + LDX]));
+                            accT = mfma16_bf(a, b, accT);
+                        }
+                    }
+                }
+            }
+            barrier();   // all reads of dZ1 / X / A_k done before the next round overwrites them
+        }  // rounds of one macro-tile
+
+        // ---------- flush of the cell's gradient sums
+        {
+            const int ln = opaque_i(lane), g = ln >> 4;
+            combine_g1_lanes_q<Q>(g1s, blk_off1, blk, ln, lw, packed, pk, pk_lc);
+            bool flush = true;
+            constexpr int REGION = S::SPW / 2;                             // floats per wave
+            if (NIC_GROUP_SUM && rg > 0) {                                  // segment-uniform: groups of one macro-tile sit in one workgroup
+                lds_f* const reg0 = (lds_f*)img0;
+                static_assert((I::NG0V + I::NG1V) * 64 * 2 <= S::SCRATCH, "group-sum scratch");
+                int leader = wave;
+                if (tile_ok)
+                    for (int w = wave - 1; w >= 4 * kh; --w)
+                        if (seg_tile0 + ((base + w) >> rg) == tile) leader = w;
+                if (leader != wave) {
+                    lds_f* const mine = opaque(reg0 + wave * REGION + ln);
+#pragma unroll
+                    for (int i = 0; i < I::NG0V; ++i) mine[i * 64] = dxacc[i >> 2][i & 3];
+#pragma unroll
+                    for (int i = 0; i < I::NG1V; ++i) mine[(I::NG0V + i) * 64] = g1s[i];
+                }
+                barrier();
+                if (leader == wave && tile_ok) {
+                    for (int w = wave + 1; w < 4 * kh + 4; ++w) {
+                        if (base + w >= t_end || seg_tile0 + ((base + w) >> rg) != tile) break;
+                        lds_cf* const theirs = opaque(reg0 + w * REGION + ln);
+#pragma unroll
+                        for (int i = 0; i < I::NG0V; ++i) dxacc[i >> 2][i & 3] += theirs[i * 64];
+#pragma unroll
+                        for (int i = 0; i < I::NG1V; ++i) g1s[i] += theirs[(I::NG0V + i) * 64];
+                    }
+                }
+                barrier();
+                flush = leader == wave;
+            }
+            constexpr bool SHARE_XY = !Q::TETRA;                            // method 4's tetrahedra share no corner along x or y
+            if (SHARE_XY && NIC_Q16_PREADD && flush && !packed) preadd_x_q<NG0T>(dxacc, blk_off0, ln);
+            if (SHARE_XY && NIC_Q16_PREADD >= 2 && rg == 0 && !packed) {    // segment-uniform
+                static_assert((I::NG0V + 1) * 64 * 2 <= S::SCRATCH, "pre-add scratch");
+                preadd_y_q<NG0T>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, REGION, barrier);
+            }
+            if (flush) {
+                const uint32_t pb0 = (uint32_t)p.g0.plane * 4u, pb1 = (uint32_t)p.g1.plane * 4u;
+#pragma unroll
+                for (int e = 0; e < Q::NG0; ++e) {
+                    uint32_t nz0 = 0u;
+#pragma unroll
+                    for (int c = 0; c < kC; ++c) nz0 |= __builtin_bit_cast(uint32_t, dxacc[(e * kC + c) >> 2][(e * kC + c) & 3]);
+                    if ((nz0 << 1) != 0u) {
+                        int dx, dy, dz;
+                        q_g0_corner<Q>(g, e, dx, dy, dz);
+                        uint32_t ob = (blk_off0 + (uint32_t)p.g0.at(dx, dy, dz)) * 4u;
+                        char* gbase = reinterpret_cast<char*>(p.g0_grad);
+#pragma unroll
+                        for (int c = 0; c < kC; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), dxacc[(e * kC + c) >> 2][(e * kC + c) & 3]);
+                    }
+                }
+                uint32_t nz1 = 0u;
+#pragma unroll
+                for (int i = 0; i < I::NG1V; ++i) nz1 |= __builtin_bit_cast(uint32_t, g1s[i]);
+                if ((nz1 << 1) != 0u) {
+#pragma unroll
+                    for (int c8 = 0; c8 < Q::K1; ++c8) {
+                        int dx, dy, dz;
+                        q_g1_corner<Q>(c8, dx, dy, dz);
+                        uint32_t ob = (blk_off1 + (uint32_t)p.g1.at(dx, dy, dz)) * 4u + (uint32_t)(3 * g) * pb1;
+                        char* gbase = reinterpret_cast<char*>(p.g1_grad);
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), g1s[c8 * 3 + cc]);
+                    }
+                }
+            }
+        }
+    }  // macro-tile loop
+  }  // segments
+
+    // ---------------- one record per workgroup
+    float* rec = p.partials + (int64_t)blockIdx.x * S::REC;
+#pragma unroll
+    for (int k = 0; k < S::NACC; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rec[S::REC_W + (wave * S::NACC + k) * 1024 + r * 64 + lane] = accW[k][r];
+    if constexpr (HALF) {
+        if (kh == S::TAIL_HALF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[S::REC_TAIL + wave * 256 + r * 64 + lane] = accT[r];
+        }
+    }
+    float* tail = rec + S::REC_WAVE + wave * S::WTAIL;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) tail[k * 64 + lane] = accBH[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tail[NH * 64 + 64 * c + lane] = accWOq[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = c < 3 ? accBO[c] : accLoss;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) tail[NH * 64 + 192 + c] = v;
+    }
+}
+
+// =====================================================================================================
+// Fixed-order reduction of the records of fused_q16_kernel.  Output index space, layer by layer:
+// W1 [64][Cin] | b1 [64] | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
+template <class Q, int NL>
+__global__ void __launch_bounds__(256) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+    using S = LdsQ<Q, NL>;
+    using I = QInfo<Q>;
+    constexpr int NH = S::NH, KF = I::KF;
+    constexpr int N_W1 = kH * Q::CIN, N_HID = kH * kH + kH;
+    constexpr int N_OUT = N_W1 + kH + NH * N_HID + 3 * kH + 3 + 1;
+    __shared__ float red[8][32];
+    const int slice = threadIdx.x >> 5;
+    const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool live = gid < N_OUT;
+    int nsrc = 0, off0 = 0, stride = 0;
+    float* dst = nullptr;
+    auto tile32 = [](int i, int j) { return ((i & 3) + 4 * (i >> 3)) * 64 + j + 32 * ((i >> 2) & 1); };      // element (row i, column j) of a 32x32 accumulator tile
+    if (live) {
+        int t = gid;
+        if (t < N_W1 + kH) {
+            int o, ch;
+            if (t < N_W1) { o = t / Q::CIN; ch = t - o * Q::CIN; dst = gr.w[0] ? gr.w[0] + t : nullptr; }
+            else { o = t - N_W1; ch = kSlotOne; dst = gr.b[0] ? gr.b[0] + o : nullptr; }        // db1 rode through dW1 on the constant-one column
+            const int r = I::rho_of_channel(ch), po = pos16(o);
+            nsrc = 1;
+            if (r < 32 * KF) {
+                // phase NH: the tile's owner wave and accumulator slot (LdsQ)
+                int w, slot;
+                if (I::NT1 == 4) { w = 4 * (NH & 1) + 2 * (po >> 5) + (r >> 5); slot = NH >> 1; }
+                else { w = 4 * (po >> 5) + (r >> 5); slot = (w >> 2) == (NH & 1) ? NH >> 1 : S::XSLOT; }
+                off0 = S::REC_W + (w * S::NACC + slot) * 1024 + tile32(po & 31, r & 31);
+            } else {
+                const int m = po & 15;
+                off0 = S::REC_TAIL + (4 * S::TAIL_HALF + (po >> 4)) * 256 + (m & 3) * 64 + 16 * (m >> 2) + (r - 32 * KF);
+            }
+        } else {
+            t -= N_W1 + kH;
+            if (t < NH * N_HID) {
+                const int k = t / N_HID, u = t - k * N_HID;
+                if (u < kH * kH) {
+                    const int o = u / kH, i = u - o * kH;
+                    const int po = pos16(o), pi = pos16(i);
+                    const int j = NH - 1 - k;                                   // the layer's phase: owner half j & 1, slot j >> 1
+                    off0 = S::REC_W + ((4 * (j & 1) + 2 * (po >> 5) + (pi >> 5)) * S::NACC + (j >> 1)) * 1024 + tile32(po & 31, pi & 31);
+                    nsrc = 1;
+                    dst = gr.w[1 + k] ? gr.w[1 + k] + u : nullptr;
+                } else {
+                    off0 = S::REC_WAVE + k * 64 + pos16(u - kH * kH); nsrc = 8; stride = S::WTAIL;
+                    dst = gr.b[1 + k] ? gr.b[1 + k] + (u - kH * kH) : nullptr;
+                }
+            } else {
+                t -= NH * N_HID;
+                nsrc = 8; stride = S::WTAIL;
+                if (t < 3 * kH) {
+                    const int c = t / kH, i = t - c * kH;
+                    off0 = S::REC_WAVE + NH * 64 + 64 * c + pos16(i);
+                    dst = gr.w[NL - 1] ? gr.w[NL - 1] + t : nullptr;
+                } else if (t < 3 * kH + 3) {
+                    off0 = S::REC_WAVE + NH * 64 + 192 + (t - 3 * kH);
+                    dst = gr.b[NL - 1] ? gr.b[NL - 1] + (t - 3 * kH) : nullptr;
+                } else {
+                    off0 = S::REC_WAVE + NH * 64 + 195;
+                    dst = loss;
+                }
+            }
+        }
+    }
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
+    const int per = (n_rec + 7) >> 3;
+    const int w_lo = slice * per, w_hi = (w_lo + per < n_rec) ? w_lo + per : n_rec;
+    if (live && dst != nullptr) {
+        for (int k = 0; k < nsrc; ++k) {
+            const float* src = partials + off0 + k * stride;
+            int w = w_lo;
+            for (; w + 8 <= w_hi; w += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part[j] += src[(int64_t)(w + j) * S::REC];
+            }
+            for (; w < w_hi; ++w) part[0] += src[(int64_t)w * S::REC];
+        }
+    }
+    red[slice][threadIdx.x & 31] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (slice != 0 || !live || dst == nullptr) return;
+    float acc = red[0][threadIdx.x];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
+    *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
+}
+
+}  // namespace nic

@@ -1,0 +1,37 @@
+// Explicit instantiations of fused_q16_kernel, one translation unit per layout (fused_q1.hip .. fused_q4.hip) so they compile in parallel.
+#pragma once
+#include "fused_q16.hpp"
+#include "fused_t16.hpp"
+
+namespace nic {
+
+template <class Q, int NL>
+static int launch_q16_nl(int mode, const FusedParams& p, int grid, hipStream_t s) {
+    const dim3 g(grid), b(512);
+    if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_MSE, NL>), g, b, 0, s, p);
+    else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_IMG, NL>), g, b, 0, s, p);
+    else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_DY, NL>), g, b, 0, s, p);
+    else return NIC_E_UNSUPPORTED;
+    return (int)hipGetLastError();
+}
+template <class Q, int NL>
+static int reduce_q16_nl(const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+    constexpr int n_out = kH * Q::CIN + kH + (NL - 2) * (kH * kH + kH) + 3 * kH + 3 + 1;
+    hipLaunchKernelGGL((reduce_q16_kernel<Q, NL>), dim3((n_out + 31) / 32), dim3(256), 0, s, partials, n_rec, g, loss, loss_scale);
+    return (int)hipGetLastError();
+}
+
+#define NIC_INSTANTIATE_Q16(METHOD)                                                                                              \
+    template <>                                                                                                                  \
+    int launch_q16<METHOD>(int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s) {                              \
+        return n_linear == 5 ? launch_q16_nl<QL<METHOD>, 5>(mode, p, grid, s) : launch_q16_nl<QL<METHOD>, 3>(mode, p, grid, s);  \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int reduce_q16<METHOD>(int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
+        return n_linear == 5 ? reduce_q16_nl<QL<METHOD>, 5>(partials, n_rec, g, loss, loss_scale, s)                             \
+                             : reduce_q16_nl<QL<METHOD>, 3>(partials, n_rec, g, loss, loss_scale, s);                            \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int q16_record_floats<METHOD>(int n_linear) { return n_linear == 5 ? LdsQ<QL<METHOD>, 5>::REC : LdsQ<QL<METHOD>, 3>::REC; }
+
+}  // namespace nic

@@ -10,4 +10,11 @@ int train16_record_floats();
 int launch_mlpn(int layout, int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s);
 int launch_reducen(int layout, int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
 int mlpn_record_floats(int n_linear);
+// plain-bf16 kernels, every layout (fused_q1.hip .. fused_q4.hip; layout id = QL<> method: 1, 2: 2D triangular / sinusoidal PE, 3, 4: the 3D methods)
+template <int METHOD>
+int launch_q16(int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s);
+template <int METHOD>
+int reduce_q16(int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+template <int METHOD>
+int q16_record_floats(int n_linear);
 }  // namespace nic

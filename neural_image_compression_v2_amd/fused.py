@@ -84,6 +84,7 @@ class PathGeometry:
     split_tile32: bool = False           # with split_bf16, 2D training: the 4-wave x 32-sample kernel instead of the 8-wave x 16-sample default
     max_workgroups: int = 0              # > 0: the launch takes at most this many workgroups (concurrent fits on separate streams share the CUs)
     mlpn: bool = False                   # 3-layer decoders on the depth-generic kernel that serves 5-layer ones (NIC_FLAG_MLPN: cross-check)
+    bf16: bool = False                   # training steps: PLAIN bf16 products (NIC_FLAG_BF16; every layout, 3 or 5 Linear layers) - the north star's "bf16"
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -147,6 +148,8 @@ class PathGeometry:
             d.flags |= _lib.NIC_FLAG_SPLIT_TILE32
         if self.mlpn:
             d.flags |= _lib.NIC_FLAG_MLPN
+        if self.bf16:
+            d.flags |= _lib.NIC_FLAG_BF16
         if g0.dtype != g1.dtype:
             raise ValueError("G0 and G1 must share a dtype")
         if g0.dtype == torch.bfloat16:
@@ -468,8 +471,10 @@ class StepPlan:
         offs, sizes, total = grad_bucket_layout(geo, self.g0, self.g1, nl)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
         views = [self.flat[o:o + s] for o, s in zip(offs, sizes)]
-        # the loss of step k goes to slot k % LOSS_SLOTS of a buffer of its own: the value a step returns stays valid (for 65 536 steps)
-        # without a copy out of the reused bucket (the copy kernel was 4.7 us of a 218 us step)
+        # the loss of step k goes to slot k % LOSS_SLOTS of a buffer of its own: the value a step returns stays valid without a copy out of
+        # the reused bucket (the copy kernel was 4.7 us of a 218 us step).  When the slots run out the plan moves on to a FRESH buffer: the
+        # views handed out so far keep the old one alive, so a loss history of any length stays correct (the reference's launchers run
+        # NUM_EPOCHS = 320 000 on one plan; 256 KB per 65 536 steps)
         self.loss_buf = torch.zeros(self.LOSS_SLOTS, dtype=torch.float32, device=self.dev)
         self.loss_base = self.loss_buf.data_ptr()
         self.steps = 0
@@ -516,6 +521,9 @@ class StepPlan:
                         raise IndexError(f"axis {a}: crop origin {min(col)}..{max(col)} outside [0, {self.hi[a]}] (image / grid bounds)")
                 org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
             slot = self.steps % self.LOSS_SLOTS
+            if slot == 0 and self.steps > 0:
+                self.loss_buf = torch.zeros(self.LOSS_SLOTS, dtype=torch.float32, device=self.dev)
+                self.loss_base = self.loss_buf.data_ptr()
             self.steps += 1
             d = self.d
             d.noise_mode = int(noise_mode)

@@ -211,7 +211,7 @@ class ImageCompression:
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
-                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16))
+                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16), bf16=bool(c.TF_PLAIN_BF16))
             if isinstance(target, fused.TargetImage) and not os.environ.get("NIC_NO_PLAN"):
                 # the steady state: one prepared launch plan (and one reused gradient bucket) per (level, LOD)
                 plans = self.__dict__.setdefault("_plans", {})
@@ -233,7 +233,7 @@ class ImageCompression:
             loss = out.loss if out.loss.data_ptr() != out.flat.data_ptr() else out.loss.clone()   # a slot of the reused bucket is rewritten by the next step
         elif c.DECODER_LINEAR_LAYERS != 3:
             # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
-            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16),
+            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16), bf16=bool(c.TF_PLAIN_BF16),
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE, noise_seed=noise_seed, noise_offset=epoch)
             y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
             loss = ((y - target) ** 2).mean()
@@ -254,7 +254,9 @@ class ImageCompression:
             loss.backward()
         self.optimizer.step()                             # Adam of both groups + the clamp of :269, one launch
         if plan_used is not None and isinstance(self.optimizer, FusedAdam):
-            plan_used.clean = True                        # .. which also zeroed the grid gradients of the bucket it read
+            # .. which also zeroed the grid gradients of the bucket it read - when it really did (NIC_ADAM_ZERO_GRAD on both buffers);
+            # otherwise the plan zeroes the bucket itself before its next launch
+            plan_used.clean = self.optimizer.zeroed_in_last_step(plan_used.gg0, plan_used.gg1)
         self.scheduler.step()
         if not isinstance(self.optimizer, FusedAdam):
             fp_quantize_clamp(fp, fl, c.FP_BITS)                                                       # :269
@@ -294,7 +296,8 @@ class ImageCompression:
         return False
 
     def train_models(self, fp, fused_step: bool = True, log_every: int = 0):
-        """image_compression.py:215-303 without the tensorboard / file side effects.  After 95 % of the steps the grids are
+        """image_compression.py:215-303 without the tensorboard / file side effects.  NOTE: FusedAdam zeroes the grid gradients it has read
+        (NIC_ADAM_ZERO_GRAD), so after a step ``grid.grad`` reads as zeros where torch.optim.Adam leaves the gradient in place.  After 95 % of the steps the grids are
         frozen and training continues on quantised copies (local rebinding, like the reference); losses stay on the
         device (no per-step host sync)."""
         c = self.cfg

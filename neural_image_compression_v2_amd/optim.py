@@ -44,6 +44,13 @@ class FusedAdam(torch.optim.Optimizer):
             self._zero.add(id(p))
         self._cache = None
 
+    def zeroed_in_last_step(self, *grads: torch.Tensor) -> bool:
+        """True when the last ``step()`` launched every one of these gradient buffers with ``NIC_ADAM_ZERO_GRAD`` - i.e. they are known to be
+        zero now.  ``fused.StepPlan.clean`` is set from this, never assumed: an optimiser rebuilt without ``zero_grad_in_step``, or a
+        parameter outside its groups, leaves the plan to zero its bucket itself."""
+        z = getattr(self, "_zeroed", frozenset())
+        return all(g is not None and g.data_ptr() in z for g in grads)
+
     def set_clamp(self, params: Iterable[torch.Tensor], lo: float, hi: float) -> None:
         """clamp these parameters to [lo, hi] right after their update (fp_quantize_clamp, fp_def.py:227-232)"""
         for p in params:
@@ -67,6 +74,7 @@ class FusedAdam(torch.optim.Optimizer):
             return loss
         # groups that share (betas, eps) - the reference's two groups do - go into the same launch; lr is per tensor
         batches: Dict[Tuple[float, float, float], list] = {}
+        zeroed = set()
         keep = []                                                # contiguous gradient copies must outlive the launch
         device: Optional[torch.device] = None
         for group in self.param_groups:
@@ -82,6 +90,9 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: all parameters must live on one device")
                 g = _lib.require_cuda_f32(p.grad, "gradient")
                 keep.append(g)
+                zero_here = id(p) in self._zero and g.data_ptr() == p.grad.data_ptr()   # a contiguous COPY of the gradient is not the buffer to zero
+                if zero_here:
+                    zeroed.add(g.data_ptr())
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0)               # host scalar, like torch's default (capturable=False)
@@ -93,7 +104,9 @@ class FusedAdam(torch.optim.Optimizer):
                 entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                   p.numel(), int(st["step"].item()), float(group["lr"]), lo, hi,
                                                   0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2),
-                                                  _lib.NIC_ADAM_ZERO_GRAD if id(p) in self._zero else 0))
+                                                  _lib.NIC_ADAM_ZERO_GRAD if zero_here else 0))
+                if id(p) in self._zero and not zero_here:
+                    p.grad.zero_()                               # the promise holds for the caller's own buffer too
                 device = p.device
         for (b1, b2, eps), entries in batches.items():
             for i in range(0, len(entries), _lib.NIC_ADAM_MAX_TENSORS):
@@ -101,6 +114,7 @@ class FusedAdam(torch.optim.Optimizer):
                 arr = (_lib.NicAdamTensor * len(chunk))(*chunk)
                 with torch.cuda.device(device):
                     _lib.check(lib.nic_adam_multi(arr, len(chunk), b1, b2, eps, _lib.stream_ptr(device)), "nic_adam_multi")
+        self._zeroed = frozenset(zeroed)
         self._remember(batches, device)
         return loss
 

@@ -42,6 +42,9 @@ class Settings:
     TF_SPLIT_BF16: bool = True           # not in the reference: fused training steps and decodes run their matrix products as hi + lo bf16
                                          # pairs on the bf16 matrix pipe (2D: all of them, 1.8x; 3D: the chained ones, 1.2x; gradients within
                                          # 5e-6 of the fp32 kernels).  False: fp32 MFMAs throughout
+    TF_PLAIN_BF16: bool = False          # not in the reference: fused training steps in PLAIN bf16 products (NIC_FLAG_BF16: one bf16 value per operand, fp32
+                                         # accumulation; every layout, 3 or 5 Linear layers; 1.5x (2D) / 2.5x (3D) faster than the split products; results
+                                         # within ~1e-2 of fp32 arithmetic - BASELINE.json's "bf16").  Decodes stay on the split / fp32 inference kernels
     DECODER_LINEAR_LAYERS: int = 3       # not in the reference (depth is hard-coded at 3, image_compression.py:57-64): 5 = the "4 x 64" decoder of
                                          # the north star; served by the fused 2D step / decode with TF_SPLIT_BF16
     TF_DEVICE_SAMPLER: bool = False      # not in the reference: LOD and crop origins from the counter-based device sampler (sampler.py) and targets
