@@ -7,21 +7,33 @@ on BASELINE.json's configs[1]: a 3840 x 2160 RGB fit, dense G0/G1 grid pair (ref
 
 N > 1: when no rank environment is present this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
 as a CHILD (before anything touches the GPU), relays its output and exits with its code; under torch.distributed.run (the driver's
-own launch) it is one rank and insists on WORLD_SIZE == --gpus.  N > 1 is weak scaling (8.29 Mpx per rank and step).  Default
---shard stripes: rank r owns a stripe of the image's second axis (a contiguous block of grid node rows) and takes its N passes per
-step from it - the same sample multiset as N replicas each covering the image once, but the step exchanges only the loss, the decoder
-gradients and one boundary node row per neighbour pair (0.3 MB at N = 8) instead of the dense grid gradients (31 MB, --shard
-replicated); the full grids are assembled once after the timed region.
+own launch) it is one rank and insists on WORLD_SIZE == --gpus.
+
+Multi-GPU shapes (one process per GPU, RCCL):
+  --scaling weak (default)    8.29 Mpx per RANK and step.  --shard stripes (default): rank r owns a stripe of the image's second axis (a
+                              contiguous block of grid node rows) and takes its N passes per step from it - the same sample multiset as N
+                              replicas each covering the image once - exchanging the loss, the decoder gradients and one boundary node row
+                              per neighbour pair (0.3 MB at N = 8); --shard replicated: every rank covers the whole image and the whole
+                              gradient bucket (31 MB) is all-reduced.
+  --scaling strong            ONE 8.29 Mpx pass per step split N ways (the north star's "the pixel batch shards across the 8 GPUs"):
+                              stripes: rank r takes its stripe once (passes = 1), same small exchange; replicated: rank r takes its
+                              stripe of SAMPLES against replicated grids and the whole bucket is all-reduced (the all-reduce-bound variant).
+  Under stripes a rank runs Adam over its own node rows only (distributed.stripe_param_blocks: 1 / N of the optimiser work, moments
+  allocated per stripe); the full grids are assembled once after the timed region.
+  --workload video --gpus N   BASELINE config 4: the 1920 x 1080 x 64 field, z-stripes of the 3D grids, same two scalings.
+  --workload fits64 --gpus N  BASELINE config 5: 64 independent 1080p fits, 64 / N per GPU back to back (replicas only, no collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract).  `value` comes from the K timed steps alone.  Beside it:
-  roofline      dominant kernel (the fused training kernel of --precision), HIP events on its launch stream: `kernel_ms` = mean over
-                the K timed steps (what `achieved` uses); `stats` = median / p10 / p90 over a separate leg of >= 100 launches run
-                after the timed region (the K = 20 of the driver's default is 45 ms - too short for percentiles)
-  roofline_f32  (or roofline_split with --precision f32) the other arithmetic mode, measured in the same run on the same inputs
-  cpu_baseline  N = 1: the CPU oracle on a bounded strip of the same workload at the fastest thread count found on the box
---precision split (default): the 2D training default, every matrix product as hi + lo bf16 pairs on the bf16 matrix pipe with fp32
-accumulation (gradients within 5e-6 of the fp32 kernel; parity-tested against the CPU oracle at the fp32 kernel's tolerances, at
-this size, with these flags: tests/test_gpu_parity.py::test_full_size_4k_properties); --precision f32: v_mfma_f32_32x32x2_f32.
+  roofline       dominant kernel (the fused training kernel of --precision), HIP events on its launch stream: `kernel_ms` = mean over
+                 the K timed steps (what `achieved` uses); `stats` = median / p10 / p90 over a separate leg of >= 100 launches run
+                 after the timed region (the K = 20 of the driver's default is 45 ms - too short for percentiles)
+  roofline_*     the other arithmetic modes measured in the same run on the same inputs (kernel-only legs): f32 / split / bf16
+  roofline_4x64  the north star's literal configuration as a WHOLE step: 5-Linear "4 x 64" decoder, bf16 grid storage with fp32 masters,
+                 plain-bf16 products, fused step + reduce + one nic_adam_multi over 10 + 2 tensors (16-bit mirrors rewritten)
+  cpu_baseline   N = 1: the CPU oracle on a bounded strip of the same workload at the fastest thread count found on the box
+--precision split (default): every matrix product as hi + lo bf16 pairs on the bf16 matrix pipe with fp32 accumulation (gradients within
+5e-6 of the fp32 kernel; the headline stays on it so that it remains comparable with the reference's fp32 arithmetic); f32:
+v_mfma_f32_32x32x2_f32; bf16: plain bf16 products (NIC_FLAG_BF16; checked against the precision-emulating oracle, tests/test_gpu_bf16.py).
 """
 import argparse
 import json
@@ -41,18 +53,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H, W = 2160, 3840                       # first sample axis ("x", coord[0]) = image axis 0, like the reference's [3, S, S] tensors
-CIN, HID = 73, 64
-FLOP_PER_SAMPLE = 6 * (CIN * HID + HID * HID + 3 * HID)          # fwd + bwd MACs x 2 = 53,760
-BYTES_PER_SAMPLE = 8 * 12 * 4 + 2 * 8 * 12 * 4 + 3 * 4            # SURVEY 8d, fp32 params / fp32 grads / fp32 target = 1,164
+VID = (64, 1080, 1920)                  # config 4: sample axes (x <-> T, y <-> H, z <-> W); grids [12, 481, 271, 17] + [12, 241, 136, 9]
+HID = 64
 PEAK_FP32_MATRIX_TFLOPS = 157.3                                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_TFLOPS = 2500.0                                        # dense bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
-KERNEL_NAME = {"split": "fused training kernel, Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, PREC_SPLIT",
-               "f32": "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN_MSE, float, PREC_F32>"}
+TRAFFIC_SOURCE = "profiles/traffic.json"
 
 
-def synthetic_target(device):
-    """rgb = 1/2 + 1/4 sin(2 pi f_c u) cos(2 pi g_c v) + 0.05 U(-1,1), quantised to 8 bit; [N, 3] in sample order"""
+def work_per_sample(dim, method, n_linear=3, grid_bytes=4, target_bytes=4):
+    """Cin, FLOPs (fwd + bwd MACs x 2) and algorithmic bytes per sample (element-granular, no reuse: gathers at the storage
+    width, fp32 atomic read-modify-writes of the gradient tables, the target)"""
+    k0 = 4 if (dim == 2 or method == 4) else 8
+    k1 = 4 if dim == 2 else 8
+    cin = 12 * (k0 + 1) + 6 * dim + 1
+    flop = 6 * (cin * HID + (n_linear - 2) * HID * HID + 3 * HID)
+    byt = (k0 + k1) * 12 * grid_bytes + 2 * (k0 + k1) * 12 * 4 + 3 * target_bytes
+    return cin, flop, byt
+
+
+def kernel_name(dim, method, precision, n_linear):
+    if precision == "bf16":
+        return f"fused_q16_kernel<QL<{method if dim == 3 else 1}>, MODE_TRAIN, NL = {n_linear}> (8 waves x 16 samples, plain bf16 products)"
+    if dim == 2 and n_linear == 5:
+        return "fused_mlpn_kernel<Layout<1>, MODE_TRAIN, 5> (4 waves x 16 samples, split-bf16 products)"
+    if dim == 2:
+        return ("fused_train16_kernel<Layout<1>, MODE_TRAIN> (8 waves x 16 samples, split-bf16 products)" if precision == "split"
+                else "fused_kernel<Layout<1>, SRC_ENCODE, MODE_TRAIN, float, PREC_F32>")
+    return f"fused_kernel<Layout<{method}>, SRC_ENCODE, MODE_TRAIN, float, {'PREC_CHAIN' if precision == 'split' else 'PREC_F32'}>"
+
+
+DTYPE_NAME = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate"}
+
+
+def synthetic_image():
+    """rgb = 1/2 + 1/4 sin(2 pi f_c u) cos(2 pi g_c v) + 0.05 U(-1,1), quantised to 8 bit; [3, H, W] on the host"""
     g = torch.Generator().manual_seed(1234)
     u = torch.linspace(0, 1, H).view(H, 1)
     v = torch.linspace(0, 1, W).view(1, W)
@@ -61,8 +96,22 @@ def synthetic_target(device):
         f, gq = 3.0 + 2 * c, 5.0 + 3 * c
         chans.append(0.5 + 0.25 * torch.sin(2 * math.pi * f * u) * torch.cos(2 * math.pi * gq * v))
     img = torch.stack(chans) + 0.05 * (torch.rand(3, H, W, generator=g) * 2 - 1)
-    img = torch.floor(img.clamp(0, 1) * 255 + 0.5) / 255
-    return img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(device), img
+    return torch.floor(img.clamp(0, 1) * 255 + 0.5) / 255
+
+
+def synthetic_video(dev):
+    """a smooth + detail field like the image's, [3, 64, 1080, 1920] uint8 codes, built on the device (132.7 Mvox)"""
+    T, Hh, Ww = VID
+    g = torch.Generator(device=dev).manual_seed(1234)
+    t = torch.linspace(0, 1, T, device=dev).view(T, 1, 1)
+    u = torch.linspace(0, 1, Hh, device=dev).view(1, Hh, 1)
+    v = torch.linspace(0, 1, Ww, device=dev).view(1, 1, Ww)
+    chans = []
+    for c in range(3):
+        f, gq = 3.0 + 2 * c, 5.0 + 3 * c
+        ch = 0.5 + 0.25 * torch.sin(2 * math.pi * (f * u + 0.5 * t)) * torch.cos(2 * math.pi * gq * v) + 0.05 * (torch.rand(T, Hh, Ww, generator=g, device=dev) * 2 - 1)
+        chans.append(torch.floor(ch.clamp(0, 1) * 255 + 0.5).to(torch.uint8))
+    return torch.stack(chans)
 
 
 def cpu_baseline(img, steps=5, budget_s=30.0):
@@ -73,13 +122,13 @@ def cpu_baseline(img, steps=5, budget_s=30.0):
     from oracle import nic_oracle as O
     g = torch.Generator().manual_seed(0)
     fp, _ = O.create_pyramid((H // 4, W // 4), 12, 8, dim=2, no_mip=True, generator=g)
-    mlp = O.init_mlp(CIN, HID, generator=g)
+    mlp = O.init_mlp(73, HID, generator=g)
 
     def one(strip):
         tgt = img[:, :, :strip].permute(1, 2, 0).reshape(-1, 3).contiguous()
         n = H * strip
         t0 = time.perf_counter()
-        noise = (torch.rand(n, CIN) - 0.5) / 256
+        noise = (torch.rand(n, 73) - 0.5) / 256
         O.forward_backward(fp[0], fp[1], mlp, [(0, 0)], (H, strip), 0.25, 0, tgt, noise, 6)
         return n, time.perf_counter() - t0
 
@@ -135,164 +184,197 @@ def pct(xs):
             "p90": round(float(np.percentile(xs, 90)), 4), "min": round(float(xs.min()), 4), "mean": round(float(xs.mean()), 4)}
 
 
-def roofline_record(precision, kern_ms, n_launch, traffic, stats=None):
-    """SURVEY 8d figures x the samples one launch processes / the kernel's launch duration"""
-    flops = FLOP_PER_SAMPLE * n_launch / (kern_ms * 1e-3) / 1e12
-    gbs = BYTES_PER_SAMPLE * n_launch / (kern_ms * 1e-3) / 1e9
-    common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": FLOP_PER_SAMPLE, "bytes_per_sample": BYTES_PER_SAMPLE,
-              "samples_per_launch": n_launch, "kernel": KERNEL_NAME[precision]}
+def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic=None, stats=None, grid_bytes=4):
+    """SURVEY 8d figures x the samples one launch processes / the kernel's launch duration.  The binding roofline: fp32 products -> the
+    fp32 matrix pipe (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s against HBM 8 TB/s / 1 164 B = 6.9 Gpx/s); bf16-pipe products (split: three
+    MFMAs per product; plain: one) -> the algorithmic-HBM figure.  `frac_bf16_storage` is the same speed priced at the bytes
+    of 16-bit grid storage (966 B per sample in 2D) - what the fraction would be on the north star's bf16 parameters."""
+    cin, fl, byt = work_per_sample(dim, method, n_linear, grid_bytes)
+    _, _, byt16 = work_per_sample(dim, method, n_linear, 2, 2)
+    flops = fl * n_launch / (kern_ms * 1e-3) / 1e12
+    gbs = byt * n_launch / (kern_ms * 1e-3) / 1e9
+    common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": fl, "bytes_per_sample": byt,
+              "samples_per_launch": n_launch, "kernel": kernel_name(dim, method, precision, n_linear)}
+    if traffic is not None:
+        common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of round 2's build of the split kernel, not measured in this run)"
     if stats is not None:
         common["stats"] = stats
-    hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+           "frac_bf16_storage": round(byt16 * n_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "bytes_per_sample_bf16_storage": byt16}
     if precision == "f32":
-        # fp32: the matrix pipe is the tighter roofline (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s vs HBM 8 TB/s / 1 164 B = 6.9 Gpx/s)
         return {"bound": "mfma", "achieved": round(flops, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / PEAK_FP32_MATRIX_TFLOPS, 4), **common, "hbm_algorithmic": hbm}
-    # split bf16: three bf16 MFMAs per product -> matrix ceiling 2 500 / (3 x 53 760) = 15.5 Gpx/s; the algorithmic-HBM ceiling
-    # (6.9 Gpx/s) is the tighter one (SURVEY 8d), so it is the reported bound; the matrix-pipe figures ride beside it
+    mult = 3 if precision == "split" else 1
     return {"bound": "hbm", **hbm, **common,
-            "mfma_bf16": {"achieved_executed": round(3 * flops, 1), "achieved_algorithmic": round(flops, 2), "peak": PEAK_BF16_TFLOPS,
-                          "unit": "TFLOP/s", "frac_executed": round(3 * flops / PEAK_BF16_TFLOPS, 4)}}
+            "note": "algorithmic bytes: the grids live in L2 / Infinity Cache (measured HBM traffic is ~4 % of them), the kernel is issue-bound",
+            "mfma_bf16": {"achieved_executed": round(mult * flops, 1), "achieved_algorithmic": round(flops, 2), "peak": PEAK_BF16_TFLOPS,
+                          "unit": "TFLOP/s", "frac_executed": round(mult * flops / PEAK_BF16_TFLOPS, 4)}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stat-launches", type=int, default=120, help="launches of the post-run statistics leg (median / p10 / p90 of the kernel time); 0: skip")
-    ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed kernel launches before the W warm-up steps (clock ramp)")
-    ap.add_argument("--precision", choices=["split", "f32"], default="split",
-                    help="split: every matrix product of the step as hi + lo bf16 pairs on the bf16 matrix pipe, fp32 accumulate (gradients "
-                         "within 5e-6 of the fp32 kernel; the product's default for 2D training); f32: v_mfma_f32_32x32x2_f32 throughout")
-    ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
-                    help="tensor: resident fp32 [N,3] targets (the reference's crop stack, built once); image: targets read from the "
-                         "resident RGBX uint8 image inside the step (a third of the bytes, one dword load per sample)")
-    ap.add_argument("--shard", choices=["stripes", "replicated"], default="stripes",
-                    help="N > 1.  stripes: every rank owns a stripe of the image's second axis (a contiguous block of grid node rows) and "
-                         "takes its N passes per step from it; the step exchanges the loss, the decoder gradients and one boundary node "
-                         "row per neighbour pair (~0.3 MB) instead of the dense grid gradients.  replicated: every rank covers the whole "
-                         "image once per step and the whole gradient bucket (31 MB) is all-reduced")
-    ap.add_argument("--virtual-world", type=int, default=0,
-                    help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
-    ap.add_argument("--workload", default="4k", choices=["4k", "lut33", "vol64", "vol128", "video", "default", "default3d", "fits8"],
-                    help="4k (default): BASELINE configs[1], the headline; the others: bench_workloads.py (configs 3 - 5 and the reference's default "
-                         "step, one GPU, same JSON shape - records for profiles/, the driver runs the default only)")
-    ap.add_argument("--launch-check", action="store_true",
-                    help="plumbing check of the N-rank launch (tests, no GPU): ranks rendezvous over gloo, sum their ranks, rank 0 prints a JSON line")
-    args = ap.parse_args()
+class Fit:
+    """One coordinate-network fit on one GPU: grids (fp32 masters, optional 16-bit mirrors the kernels gather from), decoder, Adam state,
+    the reused gradient bucket and the one-launch optimiser table (built once, step counts and learning rates rewritten per step)."""
 
-    if args.gpus < 1:
-        ap.error("--gpus must be >= 1")
-    if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
-
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
-        sys.exit(2)
-    if args.launch_check:
-        dist.init_process_group("gloo")
-        t = torch.tensor([float(rank)])
-        dist.all_reduce(t)
-        if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rank_sum": float(t.item())}), flush=True)
-        dist.destroy_process_group()
-        return
-
-    if args.workload != "4k":
-        if world != 1:
-            ap.error("--workload runs on one GPU")
-        import bench_workloads
-        bench_workloads.run(args)
-        return
-    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        backend = os.environ.get("NIC_DIST_BACKEND", "nccl")         # "gloo": rehearsal of the N > 1 path on a box with one GPU
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-        assert dist.get_world_size() == args.gpus
-
-    from neural_image_compression_v2_amd import _lib, fp_def, fused
-    from neural_image_compression_v2_amd.distributed import all_reduce_flat, assemble_stripes, plan_stripes, stripe_exchange
-    from neural_image_compression_v2_amd.image_compression import ColorDecoder
-    lib = _lib.load()
-
-    torch.manual_seed(0)                                              # same init on every rank (replicated parameters)
-    fp, _ = fp_def.create_pyramid((H // 4, W // 4), 12, 8, dev, torch.float32, True)      # [12, 961, 541], [12, 481, 271]
-    dec = ColorDecoder(CIN, HID).to(dev)
-    params = [p.detach() for p in dec.linear_params()]
-    g0, g1 = fp[0].detach(), fp[1].detach()
-    target, img = synthetic_target(dev)
-    if args.target == "image":                                        # 8-bit codes of the same image, resident and RGBX-interleaved: u / 255 = img exactly
-        from neural_image_compression_v2_amd.sampler import rgbx_interleave
-        target = fused.TargetImage(rgbx_interleave(torch.round(img * 255).to(torch.uint8).to(dev)), 255.0, rgbx=True)
-    n_local = H * W
-    vworld = args.virtual_world if world == 1 and args.virtual_world > 1 else world
-    n_global = n_local * vworld
-    stripes = vworld > 1 and args.shard == "stripes"
-    if stripes:
-        # rank r: the stripe [start, start + size) of image axis 1, `world` passes over it per step (nic_path_desc.passes)
-        plan = plan_stripes(W, 8, rank, vworld)                       # G1 cell = 8 pixels at step 1/4
-        extent, ncrops, passes = (H, plan.size), 1, vworld            # one crop, `world` passes: a cell's gradients leave the CU once
-        org = torch.tensor([[0, plan.start]], dtype=torch.int32, device=dev)
-        if args.target == "tensor":
-            target = img[:, :, plan.start:plan.start + plan.size].permute(1, 2, 0).reshape(-1, 3).repeat(vworld, 1).contiguous().to(dev)
-    else:
-        extent, ncrops, passes = (H, W), 1, 1
-        org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
-    n_mine = extent[0] * extent[1] * ncrops * passes                  # = n_local unless the stripes are uneven (W / 8 px not a multiple of N)
-    base_mine = H * plan.start * vworld if stripes else rank * n_local   # global id of this rank's first sample
-    offs, sizes, total = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, extent, ncrops), g0, g1)
-    flat = torch.zeros(total, dtype=torch.float32, device=dev)
-    tensors = params + [g0, g1]                                       # Adam state per tensor, order of the bucket (after the loss)
-    m_state = [torch.zeros_like(t) for t in tensors]
-    v_state = [torch.zeros_like(t) for t in tensors]
-    lrs = [0.005] * 6 + [0.01, 0.01]                                  # image_compression.py:361-364
-    q_lo = -(2 ** 8 - 1) / 2 ** 9
-    total_steps = args.warmup + args.steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    stream = _lib.stream_ptr(dev)
-    adam_tab = (_lib.NicAdamTensor * len(tensors))()
-
-    def geometry(i, precision):
-        return fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, passes=passes,
-                                  noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i,
-                                  sample_base=base_mine, loss_scale=1.0 / (3.0 * n_global),
-                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED,  # origins are multiples of the G1 cell
-                                  split_bf16=precision == "split")
-
-    def step(i, events=None):
-        out = fused.fused_forward_backward(geometry(i, args.precision), g0, g1, org, params, target, flat=flat, events=events)
-        if world > 1 and stripes:
-            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)   # RCCL sum of [loss | decoder grads | boundary rows]
-        elif stripes:                                                 # --virtual-world: the pack / unpack launches without the collective
-            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1, reduce=lambda t, g: None)
+    def __init__(self, dev, dim, method, grid_base=None, shapes=None, n_linear=3, precision="split", grid_dtype=torch.float32, seed=0):
+        from neural_image_compression_v2_amd import _lib, fp_def, fused
+        from neural_image_compression_v2_amd.image_compression import ColorDecoder
+        self._lib, self.fused, self.lib = _lib, fused, _lib.load()
+        self.dev, self.dim, self.method, self.nl, self.precision = dev, dim, method, n_linear, precision
+        self.cin = work_per_sample(dim, method)[0]
+        torch.manual_seed(seed)                                       # same init on every rank (replicated parameters)
+        if shapes is not None:
+            q_lo = -(2 ** 8 - 1) / 2 ** 9
+            fp = [(0.5 - q_lo) * torch.rand(*sh, device=dev) + q_lo for sh in shapes]
         else:
-            all_reduce_flat(out.flat)                                 # RCCL sum of [loss | decoder grads | grid grads]
-        cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))  # CosineAnnealingLR(T_max), eta_min = 0
-        grads = out.grad_mlp + [out.grad_g0, out.grad_g1]
-        for k, (p, g, m, v) in enumerate(zip(tensors, grads, m_state, v_state)):
-            lo, hi = (q_lo, 0.5) if k >= 6 else (1.0, -1.0)           # fp_quantize_clamp on the grids only
-            adam_tab[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), i + 1, lrs[k] * cos, lo, hi)
-        _lib.check(lib.nic_adam_multi(adam_tab, len(tensors), 0.9, 0.999, 1e-8, stream), "nic_adam_multi")   # Adam + clamp: one launch
+            mk = fp_def.create_pyramid if dim == 2 else fp_def.create_pyramid_3d
+            fp, _ = mk(grid_base, 12, 8, dev, torch.float32, True)
+        self.master = [fp[0].detach(), fp[1].detach()]
+        self.mirror = None if grid_dtype == torch.float32 else [m.to(grid_dtype) for m in self.master]
+        dec = ColorDecoder(self.cin, HID, n_linear).to(dev)
+        self.params = [p.detach() for p in dec.linear_params()]
+        self.flat = None
+        self.table = None
+        self.plan = None                                              # StripePlan: Adam over this rank's node rows only
+
+    @property
+    def grids(self):
+        return self.mirror if self.mirror is not None else self.master
+
+    def geometry(self, i, extent, ncrops=1, passes=1, sample_base=0, n_global=None, aligned=True, precision=None):
+        _lib = self._lib
+        pr = precision or self.precision
+        return self.fused.PathGeometry(dim=self.dim, method=self.method, step_number=0.25, mip_level=0, extent=tuple(extent), num_crops=ncrops,
+                                       passes=passes, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, sample_base=sample_base,
+                                       loss_scale=None if n_global is None else 1.0 / (3.0 * n_global),
+                                       flags=_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0, split_bf16=pr == "split", bf16=pr == "bf16")
+
+    def fwd_bwd(self, geo, org, target, events=None):
+        g0, g1 = self.grids
+        out = self.fused.fused_forward_backward(geo, g0, g1, org, self.params, target, flat=self.flat, events=events)
+        self.flat = out.flat
         return out
 
-    def kernel_only_leg(precision, launches):
+    def _build_table(self, out):
+        """nic_adam_tensor entries: the decoder tensors whole; the grids whole, or - stripe-sharded - one block of own node rows per channel"""
+        _lib = self._lib
+        q_lo = -(2 ** 8 - 1) / 2 ** 9
+        ent = []                                                      # (param, grad, m, v, lr, clamp, mirror)
+        for p, g in zip(self.params, out.grad_mlp):
+            ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.005, (1.0, -1.0), None))
+        for level, (p, g) in enumerate(zip(self.master, (out.grad_g0, out.grad_g1))):
+            mir = None if self.mirror is None else self.mirror[level]
+            if self.plan is None:
+                ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.01, (q_lo, 0.5), mir))
+            else:
+                from neural_image_compression_v2_amd.distributed import stripe_param_blocks, stripe_state
+                m, v = stripe_state(self.plan, level, p), stripe_state(self.plan, level, p)
+                tens = (p, g) if mir is None else (p, g, mir)
+                for c, blk in enumerate(stripe_param_blocks(self.plan, level, *tens)):
+                    ent.append((blk[0], blk[1], m[c], v[c], 0.01, (q_lo, 0.5), blk[2] if mir is not None else None))
+        for e in ent:
+            assert e[0].is_contiguous() and e[1].is_contiguous() and (e[6] is None or e[6].is_contiguous())
+        tabs = []
+        for i in range(0, len(ent), _lib.NIC_ADAM_MAX_TENSORS):
+            chunk = ent[i:i + _lib.NIC_ADAM_MAX_TENSORS]
+            arr = (_lib.NicAdamTensor * len(chunk))()
+            for k, (p, g, m, v, lr, (lo, hi), mir) in enumerate(chunk):
+                arr[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, lr, lo, hi,
+                                            0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), 0)
+            tabs.append((arr, [e[4] for e in chunk]))
+        self.table, self._keep, self._bucket = tabs, ent, out.flat.data_ptr()
+
+    def adam(self, out, i, total_steps):
+        """Adam (lr 0.005 decoder / 0.01 grids, image_compression.py:361-364) x CosineAnnealingLR(T_max) + the grids' clamp: one launch
+        (two when the stripe-sharded table exceeds NIC_ADAM_MAX_TENSORS entries)"""
+        if self.table is None or self._bucket != out.flat.data_ptr():
+            self._build_table(out)
+        cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))
+        st = self._lib.stream_ptr(self.dev)
+        for arr, lrs in self.table:
+            for k, lr in enumerate(lrs):
+                arr[k].step = i + 1
+                arr[k].lr = lr * cos
+            self._lib.check(self.lib.nic_adam_multi(arr, len(lrs), 0.9, 0.999, 1e-8, st), "nic_adam_multi")
+
+    def n_params(self):
+        return sum(p.numel() for p in self.params) + sum(g.numel() for g in self.master)
+
+
+def run_sharded(args, rank, world, dev):
+    """the 4K image (2D) or the video field (3D, config 4): whole-domain passes, weak or strong scaling, stripes or replicated"""
+    from neural_image_compression_v2_amd import _lib, fused, models, utils
+    from neural_image_compression_v2_amd.distributed import all_reduce_flat, assemble_stripes, plan_stripes, stripe_exchange
+    video = args.workload == "video"
+    dim, method = (3, args.method) if video else (2, 1)
+    full = VID if video else (H, W)                                   # sample extents; the stripe axis is the last one
+    L = full[-1]
+    n_domain = int(np.prod(full))
+    gdt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.grid_dtype]
+    if gdt != torch.float32 and args.precision == "f32":
+        raise SystemExit("16-bit grid storage needs --precision split (2D) or bf16")
+    fit = Fit(dev, dim, method, grid_base=tuple(s // 4 for s in full), n_linear=args.decoder, precision=args.precision, grid_dtype=gdt)
+    vworld = args.virtual_world if world == 1 and args.virtual_world > 1 else world
+    strong = args.scaling == "strong"
+    stripes = vworld > 1 and args.shard == "stripes"
+    split_samples = vworld > 1 and (stripes or strong)               # the rank's crop is its stripe of the last sample axis
+    plan = plan_stripes(L, 8, rank, vworld) if split_samples else None    # G1 cell = 8 samples at step 1/4
+    if stripes:
+        fit.plan = plan
+    extent = tuple(full[:-1]) + ((plan.size,) if split_samples else (L,))
+    passes = vworld if (stripes and not strong) else 1
+    start = plan.start if split_samples else 0
+    org = torch.tensor([[0] * (dim - 1) + [start]], dtype=torch.int32, device=dev)
+    n_mine = int(np.prod(extent)) * passes
+    n_global = n_domain if strong else n_domain * vworld
+    if split_samples:
+        base_mine = int(np.prod(full[:-1])) * start * passes         # global id of this rank's first sample
+    else:
+        base_mine = rank * n_domain                                   # replicated + weak: every rank its own pass over the whole domain
+    # targets: the 4K image as an fp32 [N, 3] tensor (the reference's crop stack, built once) or read from the resident RGBX image inside the
+    # step; the video field always from the resident uint8 volume (1.6 GB as an fp32 row stack)
+    img = None
+    if video:
+        from neural_image_compression_v2_amd.sampler import rgbx_interleave
+        vol = synthetic_video(dev)
+        target = fused.TargetImage(rgbx_interleave(vol), 255.0, rgbx=True)
+        del vol
+    else:
+        img = synthetic_image()
+        if args.target == "image":
+            from neural_image_compression_v2_amd.sampler import rgbx_interleave
+            target = fused.TargetImage(rgbx_interleave(torch.round(img * 255).to(torch.uint8).to(dev)), 255.0, rgbx=True)
+        else:
+            sl = img[:, :, start:start + extent[-1]]
+            target = sl.permute(1, 2, 0).reshape(-1, 3).repeat(passes, 1).contiguous().to(dev)
+    total_steps = args.warmup + args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    n_small = [None]
+
+    def step(i, events=None):
+        out = fit.fwd_bwd(fit.geometry(i, extent, 1, passes, base_mine, n_global), org, target, events)
+        if stripes:
+            if n_small[0] is None:
+                n_small[0] = fused.grad_bucket_layout(fused.PathGeometry(dim, method, 0.25, 0, extent, 1), *fit.grids, n_linear=fit.nl)[0][1 + 2 * fit.nl]
+            small = out.flat[:n_small[0]]
+            stripe_exchange(plan, small, out.grad_g0, out.grad_g1, **({} if world > 1 else {"reduce": lambda t, g: None}))
+        else:
+            all_reduce_flat(out.flat)                                 # RCCL sum of [loss | decoder grads | grid grads]
+        fit.adam(out, i, total_steps)
+        return out
+
+    def kernel_only_leg(f, launches, precision=None, tgt=None):
         """per-launch HIP-event times of the fused kernel alone (no optimiser: the parameters stay put), same inputs and flags"""
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
-        for j in range(launches):
-            fused.fused_forward_backward(geometry(total_steps + j, precision), g0, g1, org, params, target, flat=flat, events=evs[j])
+        for j in range(launches + 3):
+            f.fwd_bwd(f.geometry(total_steps + j, extent, 1, passes, base_mine, n_global, precision=precision), org, target if tgt is None else tgt,
+                      evs[j - 3] if j >= 3 else None)
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in evs]
 
     # untimed: bring the clocks up before the W warm-up steps (a 45 ms timed region right after an idle start has no ramp margin)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        fused.fused_forward_backward(geometry(0, args.precision), g0, g1, org, params, target, flat=flat)
+        fit.fwd_bwd(fit.geometry(0, extent, 1, passes, base_mine, n_global), org, target)
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
@@ -314,82 +396,261 @@ def main():
         elapsed = float(tt.item())
     loss = float(out.loss)
     if world > 1 and stripes:
-        assemble_stripes(plan, g0, g1)                                # once, outside the timed region: the full grids on every rank
+        assemble_stripes(plan, *fit.master)                           # once, outside the timed region: the full grids on every rank
+        if fit.mirror is not None:
+            for m, p in zip(fit.mirror, fit.master):
+                m.copy_(p)
     timed_kernel_ms = [a.elapsed_time(b) for a, b in ev]               # fused kernel (+ its ~10 us partial reduction)
     kern_ms = float(np.mean(timed_kernel_ms))
-    # the metric's "+ PSNR" (outside the timed region): decode the whole image with the current parameters, PSNR with peak 2^8
-    # against the synthetic target (utils.py:117-130) - after warmup + steps optimiser steps from a random initialisation
-    from neural_image_compression_v2_amd import models, utils
-    dgeo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
-                              flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, split_bf16=args.precision == "split")
-    rec = fused.fused_forward(dgeo, g0, g1, torch.zeros(1, 2, dtype=torch.int32, device=dev), params)
-    ref_img = img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(dev)
-    psnr = float(utils.calculate_psnr(models.quantize_to_bit(rec, 8), models.quantize_to_bit(ref_img, 8)))
-    # statistics + the other arithmetic mode, after the timed region (every rank runs them: same work everywhere, no collectives)
-    other = "f32" if args.precision == "split" else "split"
-    stat_main = kernel_only_leg(args.precision, args.stat_launches) if args.stat_launches > 0 else None
-    stat_other = kernel_only_leg(other, max(args.stat_launches // 2, 10)) if args.stat_launches > 0 else None
-    # the north star's "4 x 64" decoder (5 Linear layers, 102 912 FLOP per sample) on the same grids, inputs and flags: kernel-only leg
-    stat_5 = None
+    psnr = None
+    if not video:
+        # the metric's "+ PSNR" (outside the timed region): decode the whole image with the current parameters, PSNR with peak 2^8
+        # against the synthetic target (utils.py:117-130) - after warmup + steps optimiser steps from a random initialisation
+        dgeo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1,
+                                  flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, split_bf16=args.precision != "f32")
+        rec = fused.fused_forward(dgeo, fit.master[0], fit.master[1], torch.zeros(1, 2, dtype=torch.int32, device=dev), fit.params)
+        ref_img = img.permute(1, 2, 0).reshape(-1, 3).contiguous().to(dev)
+        psnr = float(utils.calculate_psnr(models.quantize_to_bit(rec, 8), models.quantize_to_bit(ref_img, 8)))
+        del rec, ref_img
+    # statistics + the other arithmetic modes, after the timed region (every rank runs them: same work everywhere, no collectives)
+    extra = {}
     if args.stat_launches > 0:
-        torch.manual_seed(1)
-        dec5 = ColorDecoder(CIN, HID, 5).to(dev)
-        params5 = [p.detach() for p in dec5.linear_params()]
-        flat5 = None
-        ev5 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.stat_launches // 3, 10))]
-        for j in range(3 + len(ev5)):
-            o5 = fused.fused_forward_backward(geometry(total_steps + j, "split"), g0, g1, org, params5, target, flat=flat5, events=ev5[j - 3] if j >= 3 else None)
-            flat5 = o5.flat
+        stat_main = kernel_only_leg(fit, args.stat_launches)
+        if fit.mirror is None and fit.nl == 3 and vworld == 1:
+            for other in ("split", "f32", "bf16"):
+                if other != args.precision:
+                    extra[other] = kernel_only_leg(fit, max(args.stat_launches // 2, 10), precision=other)
+    else:
+        stat_main = None
+    # the north star's literal configuration as a WHOLE step (2D headline runs only): 5-Linear "4 x 64" decoder, bf16 grid storage + fp32
+    # masters, plain-bf16 products; fused step + reduce + Adam over all 12 tensors with the 16-bit mirrors rewritten.  Beside it the same
+    # decoder on the split-bf16 kernel (fp32 grids), kernel only.
+    lit = None
+    if args.stat_launches > 0 and not video and vworld == 1 and not (args.decoder == 5 and args.precision == "bf16" and gdt == torch.bfloat16):
+        f5 = Fit(dev, 2, 1, grid_base=(H // 4, W // 4), n_linear=5, precision="bf16", grid_dtype=torch.bfloat16, seed=1)
+        k5, w5 = max(args.stat_launches // 4, 10), 3
+        ev5 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k5)]
+
+        def step5(i, e=None):
+            o = f5.fwd_bwd(f5.geometry(i, extent, 1, passes, base_mine, n_global), org, target, e)
+            f5.adam(o, i, w5 + k5)
+            return o
+        for i in range(w5):
+            step5(i)
         torch.cuda.synchronize()
-        stat_5 = [a.elapsed_time(b) for a, b in ev5]
+        t5 = time.perf_counter()
+        for i in range(k5):
+            o5 = step5(w5 + i, ev5[i])
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t5) / k5
+        km5 = [a.elapsed_time(b) for a, b in ev5]
+        f5s = Fit(dev, 2, 1, grid_base=(H // 4, W // 4), n_linear=5, precision="split", seed=1)
+        ks5 = kernel_only_leg(f5s, max(args.stat_launches // 6, 10))
+        lit = (dt5, km5, float(o5.loss), ks5, k5, w5)
+        del f5s
 
     if rank == 0:
-        mpix = n_local * world * args.steps / elapsed / 1e6
+        unit = "Mvoxels/s" if video else "Mpixels/s"
+        done = n_domain * (1 if strong else world) * args.steps       # samples the whole job processed in the timed region
+        rate = done / elapsed / 1e6
+        grids_txt = " + ".join(str(list(g.shape)) for g in fit.master)
         if stripes:
-            xb = 4 * (offs[7] + (vworld - 1) * 12 * (g0.shape[2] + g1.shape[2]))
-            par = (f"dp{vworld}, grids sharded in stripes of image axis 1 ({plan.size} px = {vworld} passes per rank and step); exchange per step = "
-                   f"loss + decoder grads + {vworld - 1} boundary node rows of G0 and G1 = {xb} B all-reduced"
-                   + (" (virtual: one process, no collectives)" if world == 1 else ""))
+            xb = 4 * (n_small[0] + (vworld - 1) * 12 * sum(int(g[0, 0].numel()) for g in fit.master))
+            par = (f"dp{vworld}, {'strong' if strong else 'weak'} scaling, grids sharded in stripes of the last sample axis ({plan.size} samples x {passes} "
+                   f"pass{'es' if passes > 1 else ''} per rank and step, Adam over the rank's own node rows); exchange per step = loss + decoder grads + "
+                   f"{vworld - 1} boundary node rows of G0 and G1 = {xb} B all-reduced" + (" (virtual: one process, no collectives)" if world == 1 else ""))
+        elif vworld > 1:
+            par = (f"dp{world}, {'strong' if strong else 'weak'} scaling, replicated parameters, "
+                   f"{'the rank takes its stripe of the samples' if strong else 'every rank covers the whole domain'}; {4 * fit.flat.numel()} B all-reduced per step")
         else:
-            par = f"dp{world} (sample-sharded, replicated parameters" + (f", {4 * total} B all-reduced per step)" if world > 1 else ")")
+            par = "dp1"
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")            # HBM bytes per launch from the rocprofv3 --pmc passes, if collected
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not video and args.precision == "split" and fit.nl == 3 and fit.mirror is None:
             try:
                 traffic = json.load(open(tp)).get("fused_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
+        gb = 4 if fit.mirror is None else 2
+        dec_txt = "3xLinear(64) GELU decoder" if fit.nl == 3 else "5xLinear(64) GELU decoder (the north star's \"4 x 64\")"
+        if video:
+            wl = (f"1920x1080x64 video field as a 3D fit (BASELINE config 4), every voxel once per step and replica: dense G0 + G1 {grids_txt}, method {method} "
+                  f"({'tetrahedral G0, sinusoidal PE' if method == 4 else '8 raw G0 corners, triangular PE'}), {dec_txt}, targets from the resident RGBX volume, "
+                  "in-kernel Threefry-4x32-12 noise, MSE, fused fwd+bwd + gradient exchange + Adam + clamp")
+            metric = "Mvoxels/sec train-step (fwd+bwd), 1920x1080x64 video field, 1/2/4/8 MI355X"
+        else:
+            wl = (f"3840x2160 RGB fit, every pixel once per step: dense G0 [12,961,541] + G1 [12,481,271] grid pair (reference semantics, no-mip"
+                  f"{', ' + args.grid_dtype + ' storage with fp32 masters' if fit.mirror is not None else ''}), triangular PE, {dec_txt}, "
+                  "in-kernel Threefry-4x32-12 noise, MSE, fused fwd+bwd + grad all-reduce + Adam + clamp")
+            metric = "Mpixels/sec train-step (fwd+bwd) + PSNR, 4K RGB, 1/2/4/8 MI355X"
         res = {
-            "metric": "Mpixels/sec train-step (fwd+bwd) + PSNR, 4K RGB, 1/2/4/8 MI355X",
-            "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16x2-split operands, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "3840x2160 RGB fit, every pixel once per step: dense G0 [12,961,541] + G1 [12,481,271] grid pair "
-                                   "(reference semantics, no-mip), triangular PE, 3xLinear(64) GELU decoder, in-kernel Threefry-4x32-12 noise, MSE, "
-                                   "fused fwd+bwd + grad all-reduce + Adam + clamp",
-                       "pixels_per_step_per_gpu": n_local, "parallelism": par,
-                       "final_loss": round(loss, 6), "psnr_db_after_these_steps": round(psnr, 3)},
+            "metric": metric, "value": round(rate, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": wl, "samples_per_step_per_gpu": n_mine, "parallelism": par, "final_loss": round(loss, 6)},
         }
-        res["roofline"] = roofline_record(args.precision, kern_ms, n_mine, traffic,
-                                          {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})})
-        if stat_other:
-            # the other arithmetic mode on the same inputs in the same run: its median launch time carries the record
-            res["roofline_" + other] = roofline_record(other, float(np.median(stat_other)), n_mine, None, {"stat_leg": pct(stat_other)})
-            res["roofline_" + other]["mpix_s_kernel_only"] = round(n_mine / float(np.median(stat_other)) / 1e3, 1)
-        if stat_5:
-            f5 = 6 * (CIN * HID + 3 * HID * HID + 3 * HID)                      # 102,912
-            k5 = float(np.median(stat_5))
-            res["roofline_4x64"] = {"decoder": "Linear(73,64) + 3 x Linear(64,64) + Linear(64,3), GELU, Sigmoid (n_linear = 5)", "bound": "hbm",
-                                    "achieved": round(BYTES_PER_SAMPLE * n_mine / (k5 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": round(BYTES_PER_SAMPLE * n_mine / (k5 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                                    "kernel": "fused_mlpn_kernel<Layout<1>, MODE_TRAIN_MSE, 5> (4 waves x 16 samples, split-bf16 products)",
-                                    "kernel_ms": round(k5, 4), "stats": {"stat_leg": pct(stat_5)}, "flop_per_sample": f5,
-                                    "mpix_s_kernel_only": round(n_mine / k5 / 1e3, 1),
-                                    "mfma_bf16": {"achieved_executed": round(3 * f5 * n_mine / (k5 * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
-                                                  "unit": "TFLOP/s", "frac_executed": round(3 * f5 * n_mine / (k5 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
-        if world == 1 and not args.no_cpu_baseline:
+        if psnr is not None:
+            res["config"]["psnr_db_after_these_steps"] = round(psnr, 3)
+        res["roofline"] = roofline_record(dim, method, args.precision, fit.nl, kern_ms, n_mine, traffic,
+                                          {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})}, gb)
+        for other, xs in extra.items():
+            # another arithmetic mode on the same inputs in the same run: its median launch time carries the record
+            r = roofline_record(dim, method, other, fit.nl, float(np.median(xs)), n_mine, None, {"stat_leg": pct(xs)}, gb)
+            r["m%s_s_kernel_only" % ("vox" if video else "pix")] = round(n_mine / float(np.median(xs)) / 1e3, 1)
+            if other == "bf16":
+                r["parity"] = "against the precision-emulating oracle at 1e-3 (tests/test_gpu_bf16.py); ~5e-3 from fp32 arithmetic"
+            res["roofline_" + other] = r
+        if lit is not None:
+            dt5, km5, loss5, ks5, k5, w5 = lit
+            r = roofline_record(2, 1, "bf16", 5, float(np.median(km5)), n_mine, None, {"timed_steps": pct(km5)}, 2)
+            r.update({"decoder": "Linear(73,64) + 3 x Linear(64,64) + Linear(64,3), GELU, Sigmoid (n_linear = 5)",
+                      "grids": "bfloat16 storage (966 B per sample), fp32 masters + Adam state", "whole_step": True,
+                      "ms_per_step": round(dt5 * 1e3, 4), "steps": k5, "warmup": w5, "mpix_s": round(n_mine / dt5 / 1e6, 1),
+                      "step": "fused_q16_kernel + reduce_q16_kernel + nic_adam_multi over 10 decoder tensors + 2 grids (16-bit mirrors rewritten)",
+                      "final_loss": round(loss5, 6),
+                      "split_bf16_products_fp32_grids_kernel_only": {"kernel": kernel_name(2, 1, "split", 5), "kernel_ms": round(float(np.median(ks5)), 4),
+                                                                     "mpix_s": round(n_mine / float(np.median(ks5)) / 1e3, 1), "stats": pct(ks5)}})
+            res["roofline_4x64"] = r
+        if world == 1 and not args.no_cpu_baseline and not video:
             res["cpu_baseline"] = cpu_baseline(img)
         print(json.dumps(res), flush=True)
+
+
+def run_fits64(args, rank, world, dev):
+    """BASELINE config 5: 64 independent 1080p fits, 64 / N per GPU, one step of each per sweep, back to back (a persistent
+    workgroup keeps its CU's LDS for the whole launch, so side-by-side fits only divide the chip).  Replicas only - no collective."""
+    from neural_image_compression_v2_amd import _lib
+    HH, WW, NF = 1080, 1920, 64
+    lo = rank * NF // world
+    hi = (rank + 1) * NF // world
+    g = torch.Generator(device="cpu").manual_seed(99)
+    fits, targets = [], []
+    for k in range(NF):
+        t = torch.rand(HH * WW, 3, generator=g)                       # every rank draws the same 64 targets and keeps its own
+        if lo <= k < hi:
+            fits.append(Fit(dev, 2, 1, grid_base=(HH // 4, WW // 4), n_linear=args.decoder, precision=args.precision, seed=k))
+            targets.append(t.to(dev))
+    org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+    total = args.warmup + args.steps
+
+    def sweep(i):
+        outs = []
+        for f, t in zip(fits, targets):
+            o = f.fwd_bwd(f.geometry(i, (HH, WW)), org, t)
+            f.adam(o, i, total)
+            outs.append(o)
+        return outs
+    for i in range(args.warmup):
+        sweep(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        outs = sweep(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        rate = NF * HH * WW * args.steps / elapsed / 1e6
+        _, fl, byt = work_per_sample(2, 1, args.decoder)
+        print(json.dumps({
+            "metric": "aggregate Mpixels/sec, 64 independent 1080p fits (BASELINE config 5), 1/2/4/8 MI355X", "value": round(rate, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": f"64 x (1920 x 1080 fit, own grids [12,481,271] + [12,241,136], own {args.decoder}-Linear decoder, own Adam state); a step = one "
+                                   f"training step of every fit, {hi - lo} fits per GPU back to back on the whole chip each",
+                       "parallelism": f"replicas only: rank r owns fits [{NF}r/{world}, {NF}(r+1)/{world}), no collective", "loss_fit0": round(float(outs[0].loss), 6)},
+            "roofline": {"bound": "hbm", "achieved": round(byt * rate * 1e6 / world / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(byt * rate * 1e6 / world / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_sample": byt,
+                         "note": "per GPU, whole sweep (fused kernel + reduce + Adam of every fit) over the algorithmic bytes"}}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stat-launches", type=int, default=120, help="launches of the post-run statistics leg (median / p10 / p90 of the kernel time); 0: skip the extra legs")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed kernel launches before the W warm-up steps (clock ramp)")
+    ap.add_argument("--precision", choices=["split", "f32", "bf16"], default="split",
+                    help="split: every matrix product of the step as hi + lo bf16 pairs on the bf16 matrix pipe, fp32 accumulate (gradients "
+                         "within 5e-6 of the fp32 kernel; the product's default); f32: v_mfma_f32_32x32x2_f32 throughout; bf16: plain bf16 products")
+    ap.add_argument("--decoder", type=int, choices=[3, 5], default=3, help="Linear layers of the decoder: 3 (the reference) or 5 (the north star's \"4 x 64\")")
+    ap.add_argument("--grid-dtype", choices=["f32", "bf16", "fp16"], default="f32", help="grid STORAGE the kernels gather from (fp32 masters + Adam state either way)")
+    ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
+                    help="4k: tensor = resident fp32 [N,3] targets (the reference's crop stack, built once); image = targets read from the "
+                         "resident RGBX uint8 image inside the step (a third of the bytes, one dword load per sample)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1.  weak: the whole domain per RANK and step; strong: ONE pass over the domain per step, split N ways")
+    ap.add_argument("--shard", choices=["stripes", "replicated"], default="stripes",
+                    help="N > 1.  stripes: every rank owns a stripe of the last sample axis (a contiguous block of grid node rows); the step "
+                         "exchanges the loss, the decoder gradients and one boundary node row per neighbour pair.  replicated: replicated "
+                         "parameters, the whole gradient bucket is all-reduced")
+    ap.add_argument("--method", type=int, choices=[3, 4], default=4, help="--workload video: COMPRESSION_METHOD")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
+    ap.add_argument("--workload", default="4k", choices=["4k", "video", "fits64", "lut33", "vol64", "vol128", "slab", "default", "default3d", "fits8"],
+                    help="4k (default): BASELINE configs[1], the headline; video / fits64: configs 4 / 5 (any --gpus); the others: bench_workloads.py "
+                         "(one GPU, same JSON shape - records for profiles/; the driver runs the default only)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="plumbing check of the N-rank launch (tests, no GPU): ranks rendezvous over gloo, sum their ranks and - for the sharded "
+                         "workloads - print the per-rank plan; rank 0 prints a JSON line")
+    args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        rec = {"launch_check": True, "n_gpus": dist.get_world_size(), "rank_sum": float(t.item()), "workload": args.workload, "scaling": args.scaling}
+        if args.workload in ("4k", "video"):
+            from neural_image_compression_v2_amd.distributed import plan_stripes
+            L = VID[-1] if args.workload == "video" else W
+            plans = [plan_stripes(L, 8, r, world) for r in range(world)] if world > 1 else []
+            rec["stripes"] = [[p.start, p.size] for p in plans]
+            rec["covered"] = sum(p.size for p in plans) if plans else L
+        elif args.workload == "fits64":
+            rec["fits_per_rank"] = [(r + 1) * 64 // world - r * 64 // world for r in range(world)]
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        dist.destroy_process_group()
+        return
+
+    if args.workload not in ("4k", "video", "fits64"):
+        if world != 1:
+            ap.error(f"--workload {args.workload} runs on one GPU")
+        import bench_workloads
+        bench_workloads.run(args)
+        return
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        backend = os.environ.get("NIC_DIST_BACKEND", "nccl")         # "gloo": rehearsal of the N > 1 path on a box with one GPU
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        assert dist.get_world_size() == args.gpus
+    if args.workload == "fits64":
+        run_fits64(args, rank, world, dev)
+    else:
+        run_sharded(args, rank, world, dev)
     if world > 1:
         dist.destroy_process_group()
 

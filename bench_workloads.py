@@ -7,7 +7,7 @@ records are kept under profiles/.
              ceil(33/4)+1 = 10 and 6 nodes per axis; N = 35 937 per step (launch-latency regime)
     vol64    the 64^3 volume the reference's own sweeps use (method 3 and 4)
     vol128   a 128^3 volume, method 3 and 4
-    video    config 4, one rank's slab of the 1920 x 1080 x 64 video field (x <-> T, y <-> H, z <-> W; grids [12,481,271,17] +
+    slab     config 4, one rank's slab of the 1920 x 1080 x 64 video field (the whole field, any --gpus: bench.py --workload video) (x <-> T, y <-> H, z <-> W; grids [12,481,271,17] +
              [12,241,136,9] at full size): z in [240 r, 240 r + 240), 16.6 Mvox per step, method 4 (and 3)
     default  the reference's default step: IMAGE_SIZE 512, 8 random crops of 256 x 256, through the product's host loop
     fits8    config 5, one GPU's share: 8 independent 1080p fits, each with its own grids / decoder / optimiser state and stream -
@@ -68,6 +68,9 @@ def _adam(lib, _lib, st, out, i, total, stream):
     _lib.check(lib.nic_adam_multi(tab, 8, 0.9, 0.999, 1e-8, stream), "nic_adam_multi")
 
 
+_DT = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate"}
+
+
 def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=True, shapes=None):
     """one crop = the whole volume (or slab) per step"""
     from neural_image_compression_v2_amd import _lib, fused
@@ -84,7 +87,7 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
     def step(i, ev=None):
         nonlocal flat
         geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=tuple(extent), num_crops=1,
-                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, split_bf16=split)
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, split_bf16=args.precision == "split", bf16=args.precision == "bf16")
         out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], target, flat=flat, events=ev)
         flat = out.flat
         _adam(lib, _lib, st, out, i, total, stream)
@@ -107,8 +110,8 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
     tfl = flop * n / (km * 1e-3) / 1e12
     return {"metric": f"{unit[:-2]}/sec train-step (fwd+bwd + Adam + clamp), {name}", "value": round(n / dt / 1e6, 2), "unit": unit, "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate" if (split and dim == 3)
-                                           else ("bf16x2-split operands, f32 accumulate" if split else "f32")),
+            "vs_baseline": None, "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate"
+                                           if (args.precision == "split" and dim == 3) else _DT[args.precision]),
             "data": "synthetic",
             "config": {"workload": name, "samples_per_step": n, "extent": list(extent), "grids": [list(st["g0"].shape), list(st["g1"].shape)],
                        "method": method, "cin": cin, "final_loss": round(float(out.loss), 6)},
@@ -124,7 +127,7 @@ def _run_default(args, dev):
     import random
     from neural_image_compression_v2_amd.image_compression import ImageCompression
     from neural_image_compression_v2_amd.var2 import Settings
-    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True)
+    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16")
     S = cfg.IMAGE_SIZE
     u = torch.linspace(0, 1, S)
     img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :] for c in range(3)])
@@ -144,7 +147,7 @@ def _run_default(args, dev):
     cin, flop, byt = _work(2, 1)
     return {"metric": "Mpixels/sec train-step, the reference's default 8 x 256^2 random-crop step (host loop included)", "value": round(px / dt / 1e6, 2),
             "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x2-split operands, f32 accumulate", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": _DT[args.precision], "data": "synthetic",
             "config": {"workload": "IMAGE_SIZE 512, 8 random crops of 256 x 256 per step (var2.py defaults), targets from the resident uint8 image, "
                                    "one-launch Adam", "samples_per_step": px, "psnr_db": round(float(ic.psnr(ic.feature_pyramid)), 3)},
             "roofline": {"bound": "hbm", "achieved": round(byt * px / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -158,7 +161,7 @@ def _run_default3d(args, dev, method, size):
     from neural_image_compression_v2_amd.image_compression import ImageCompression
     from neural_image_compression_v2_amd.var2 import Settings
     cfg = Settings(IMAGE_SIZE=size, IMAGE_3D_SIZE=size, IMAGE_DIMENSION=3, COMPRESSION_METHOD=method, CROP_MIP_LEVEL=5,
-                   NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True)
+                   NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16")
     g = torch.Generator(device="cpu").manual_seed(5)
     vol = torch.randint(0, 256, (3, size, size, size), generator=g, dtype=torch.uint8)
     ic = ImageCompression(cfg, dev, seed=0)
@@ -178,7 +181,8 @@ def _run_default3d(args, dev, method, size):
     return {"metric": f"Mvoxels/sec train-step, the reference's 3D sweep shape: 8 x 32^3 random crops of a {size}^3 volume, method {method} (host loop included)",
             "value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate", "data": "synthetic",
+            "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate" if args.precision == "split" else _DT[args.precision]),
+            "data": "synthetic",
             "config": {"workload": f"IMAGE_SIZE {size}, IMAGE_DIMENSION 3, COMPRESSION_METHOD {method}, CROP_MIP_LEVEL 5, NUM_CROPS 8, targets from the resident "
                                    "uint8 volume, one-launch Adam", "samples_per_step": n, "cin": cin},
             "roofline": {"bound": "hbm", "achieved": round(byt * n / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -203,7 +207,7 @@ def _run_fits8(args, dev):
     def one(k, i, max_wg):
         st = fits[k]
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(HH, WW), num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL,
-                                 noise_seed=7 + k, noise_offset=i, split_bf16=True, max_workgroups=max_wg)
+                                 noise_seed=7 + k, noise_offset=i, split_bf16=args.precision == "split", bf16=args.precision == "bf16", max_workgroups=max_wg)
         out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], targets[k], flat=st["flat"])
         st["flat"] = out.flat
         _adam(lib, _lib, st, out, i, total, _lib.stream_ptr(dev))
@@ -256,7 +260,7 @@ def run(args):
         S = 64 if w == "vol64" else 128
         for method in (3, 4):
             recs.append(_run_volume(args, dev, f"{S}^3 volume, one crop, method {method}", 3, method, (S, S, S), S // 4, (0, 0, 0)))
-    elif w == "video":
+    elif w == "slab":
         for method in (4, 3):
             recs.append(_run_volume(args, dev, f"1920x1080x64 video field, rank 3's slab z in [720, 960) of 8, method {method}", 3, method, (64, 1080, 240),
                                     (16, 270, 480), (0, 0, 720)))

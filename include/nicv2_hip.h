@@ -304,6 +304,24 @@ typedef struct nic_adam_tensor {
 #define NIC_ADAM_ZERO_GRAD 1
 int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
 
+/* ---- multi-GPU, stripe-sharded grids (no reference counterpart - the reference is single-device): the per-step exchange buffer
+ *      [small | boundary rows of G0 | boundary rows of G1].  `small` = the head of the flat gradient bucket (loss + decoder gradients,
+ *      n_small floats); a row set = `nrows` node rows (hyper-planes of the slowest spatial axis: `row_elems` contiguous floats) of every one of
+ *      `channels` channel planes (`plane` floats apart) of one grid-gradient tensor.  nic_stripe_pack gathers everything into `buf`
+ *      (layout: small, then per set [channel][row][row_elems]); the caller all-reduces `buf` over RCCL; nic_stripe_unpack writes the sums
+ *      back.  One launch each (the torch formulation was index_select x 2 + cat + copy + index_copy x 2 per step). */
+#define NIC_STRIPE_MAX_ROWS 15
+typedef struct nic_row_set {
+    float *base;             /* the gradient tensor [C, rows, row_elems...] */
+    int64_t plane;           /* floats per channel */
+    int32_t row_elems;       /* floats per node row */
+    int32_t channels;
+    int32_t nrows;           /* <= NIC_STRIPE_MAX_ROWS */
+    int32_t rows[NIC_STRIPE_MAX_ROWS];
+} nic_row_set;
+int nic_stripe_pack(const float *small_buf, int64_t n_small, const nic_row_set *sets, int nsets, float *buf, void *stream);
+int nic_stripe_unpack(float *small_buf, int64_t n_small, const nic_row_set *sets, int nsets, const float *buf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,15 @@ class NicAdamTensor(ctypes.Structure):
                 ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+NIC_STRIPE_MAX_ROWS = 15
+
+
+class NicRowSet(ctypes.Structure):
+    """struct nic_row_set (include/nicv2_hip.h)."""
+    _fields_ = [("base", ctypes.c_void_p), ("plane", ctypes.c_int64), ("row_elems", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("nrows", ctypes.c_int32), ("rows", ctypes.c_int32 * NIC_STRIPE_MAX_ROWS)]
+
+
 class NicTargetImage(ctypes.Structure):
     """struct nic_target_image (include/nicv2_hip.h)."""
     _fields_ = [("data", ctypes.c_void_p), ("is_u8", ctypes.c_int32), ("den", ctypes.c_float), ("size", ctypes.c_int32 * 3),
@@ -106,6 +115,8 @@ SIGNATURES = {
     "nic_sampler_draw_origins": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, _P, _P]),
     "nic_rgbx_interleave": (_I, [_P, _L, _P, _P]),
     "nic_rgbx_downsample2": (_I, [_P, _I, _I, _P, _P]),
+    "nic_stripe_pack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
+    "nic_stripe_unpack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -295,7 +295,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Phase timing for a DIAGNOSTIC build (-DNIC_STAMPS, see ab/stamps.py): s_memtime at phase boundaries, per-phase sums kept in
 // scalars and dumped by lane 0 of every wave to the unused tail of the workspace.  The shipped library is built without it.
 #ifdef NIC_STAMPS
-#define NIC_NPH 14
+#define NIC_NPH 16
 #define STAMP(ph)                                                                                   \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \

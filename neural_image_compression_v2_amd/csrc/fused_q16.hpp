@@ -458,18 +458,27 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #ifndef NIC_Q16_PREADD
 #define NIC_Q16_PREADD 2
 #endif
+#ifndef NIC_Q16_SB
+#define NIC_Q16_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // =====================================================================================================
+#ifdef NIC_Q16_NVGPR
+#define NIC_Q16_ATTR __attribute__((amdgpu_waves_per_eu(NIC_Q16_NVGPR, NIC_Q16_NVGPR)))      // diagnostic: how many registers does the kernel really need?
+#else
+#define NIC_Q16_ATTR
+#endif
 template <class Q, int MODE, int NL>
-__global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
+__global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams p) {
     using S = LdsQ<Q, NL>;
     using I = QInfo<Q>;
     constexpr int NH = S::NH, D = Q::DIM, NS = Q::NS, KF = I::KF, NDX = I::NDX, NG0T = I::NG0V / 4;
     constexpr bool HALF = I::HALF;
     constexpr int LD1 = S::LD1, LDH = S::LDH, LDZ = S::LDZ, LDX = S::LDX;
     static_assert(MODE != MODE_INFER && (NL == 3 || NL == 5), "training kernel, 3 or 5 Linear layers");
-    // raw grid values gathered once per macro-tile (every sample a lane handles there lies in the same G0 / G1 cell) where the register
-    // budget of two waves per SIMD allows, otherwise at the head of every round (L1 / L2 hits): NIC_Q16_HOIST bit 0: G0, bit 1: G1
+    // raw grid values gathered once per macro-tile (every sample a lane handles there lies in the same G0 / G1 cell) and kept in registers where
+    // the budget of two waves per SIMD allows, otherwise re-fetched at the end of every round for the next one (L1 / L2 hits; dead through
+    // the forward and backward passes): NIC_Q16_HOIST bit 0: G0 kept, bit 1: G1 kept
 #ifdef NIC_Q16_HOIST
     constexpr int HOIST = NIC_Q16_HOIST;
 #else
@@ -528,6 +537,15 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
     lds_bf* const img0 = sm + S::OFF_IMG;
     auto barrier = [&]() { wg_lds_barrier(); };
 
+#ifdef NIC_STAMPS
+    // phases: 0 encode + noise | 1 forward layers | 2 dW_out, dA_last | 3 + 2 j: phase j up to its barrier, 4 + 2 j: its barrier wait + owned dW
+    // (j = 0 .. NH - 1) | 11 dX + grid sums | 12 setup + gather | 13 flush | 14 barrier + dW1 | 15 round-end barrier
+    unsigned long long stamp_sum[NIC_NPH];
+#pragma unroll
+    for (int i = 0; i < NIC_NPH; ++i) stamp_sum[i] = 0;
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave), two segments: fused_train16.hpp
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
   for (int seg = 0; seg < 2; ++seg) {
@@ -603,8 +621,9 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
             for (int t = 0; t < NDX; ++t) dxacc[t] = f32x4(0.f);
             const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};
             cell_offsets<Q>(p, qb, blk_off0, blk_off1);
-            gather_cell_q<Q, HG0, HG1>(p, blk_off0, blk_off1, g, raw);
+            gather_cell_q<Q, true, true>(p, blk_off0, blk_off1, g, raw);
         }
+        STAMP(12);
 
         for (int it = it_begin; it < it_begin + it_len; ++it) {
             // ================= forward =================
@@ -613,7 +632,6 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
             float kf[3];                                                      // G1 interpolation fractions of the sample
             {
                 const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
-                if (!HG0 || !HG1) gather_cell_q<Q, !HG0, !HG1>(p, blk_off0, blk_off1, g, raw);
                 // ---------- which sample does this lane own in this round
                 bool valid = tile_ok;
                 int64_t n;
@@ -663,6 +681,7 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                 float xs[NS];
                 encode_q<Q>(p, q, g, xs, kf, raw);
                 add_noise_q<Q>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+                STAMP(0);
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));                       // 64-column weight images: row n16, columns 8 g ..
                 lds_cf* const b_row = opaque(Bs + 4 * g);
@@ -691,13 +710,16 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                     }
                 }
                 // ---------- hidden layers: the B fragments of layer k + 1 are the image A_k of its weight gradient
+                // GELU two row tiles at a time, packed at once: a k-step's activations and derivatives are 8 + 8 registers only until they are 4 + 4
                 bf16x8 af[2];
-                {
-                    f32x4 a4[4], d4[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a4[t], d4[t]);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) { af[s] = cvt_pair(a4[2 * s], a4[2 * s + 1]); dpk[0][s] = cvt_pair(d4[2 * s], d4[2 * s + 1]); }
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 a4[2], d4[2];
+                    gelu_and_grad4(z[2 * s], a4[0], d4[0]);
+                    gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
+                    af[s] = cvt_pair(a4[0], a4[1]);
+                    dpk[0][s] = cvt_pair(d4[0], d4[1]);
+                    NIC_Q16_SB;
                 }
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
@@ -709,11 +731,15 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                         st_frag(&a_st[32 * s], af[s]);
                         kstep_b<4>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
                     }
-                    f32x4 a4[4], d4[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a4[t], d4[t]);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) { af[s] = cvt_pair(a4[2 * s], a4[2 * s + 1]); dpk[k + 1][s] = cvt_pair(d4[2 * s], d4[2 * s + 1]); }
+                    for (int s = 0; s < 2; ++s) {
+                        f32x4 a4[2], d4[2];
+                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
+                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
+                        af[s] = cvt_pair(a4[0], a4[1]);
+                        dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
+                        NIC_Q16_SB;
+                    }
                 }
                 // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); its input fragments are the
                 // image dW_out contracts with (the DZ region is free until the first dZ is stored)
@@ -756,6 +782,7 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                 }
             }
             wave_lds_fence();
+            STAMP(1);
             // ================= backward =================
             f32x4 dzc[4];                                                   // dZ of the pre-activation of the layer at hand; ends as layer 1's dZ
             {
@@ -784,6 +811,7 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                     }
                 }
             }
+            STAMP(2);
 #pragma unroll
             for (int k = NH - 1; k >= 0; --k) {
                 // phase j: hidden layer k: a_k -> z -> a_{k+1};  dzc = dZ of z
@@ -819,6 +847,7 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                         for (int r = 0; r < 4; ++r) accBH = mfma4_bf(ones, bh[r], accBH);
                     }
                 }
+                STAMP(3 + 2 * j);
                 barrier();                                                     // every wave's dZ image of this phase is in place
                 if (kh == (j & 1)) {   // dW_hidden[k] tile (to, tk) += sum over the samples of all eight waves of dZ[o][n] a_k[i][n]
                     const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
@@ -832,6 +861,7 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                     }
                 }
                 if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
+                STAMP(4 + 2 * j);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
             }
@@ -863,6 +893,14 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                     for (int cc = 0; cc < 3; ++cc) g1s[c8 * 3 + cc] = fmaf(dxacc[NG0T][cc], w, g1s[c8 * 3 + cc]);
                 }
             }
+            // not hoisted: the next round's raw values are fetched HERE - in flight across the dW1 phase and the round-end barrier, where
+            // few registers are live, and spread over the waves' drift - instead of at the head of the round, where all eight waves of the
+            // CU would queue 36+ scattered loads each on its one texture-address path at the same moment (+6.5 K cycles per round)
+            if (!HG0 || !HG1) {
+                const int g = opaque_i(lane) >> 4;
+                gather_cell_q<Q, !HG0, !HG1>(p, blk_off0, blk_off1, g, raw);
+            }
+            STAMP(11);
             barrier();
             {
                 const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
@@ -907,7 +945,9 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                     }
                 }
             }
+            STAMP(14);
             barrier();   // all reads of dZ1 / X / A_k done before the next round overwrites them
+            STAMP(15);
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
@@ -982,8 +1022,16 @@ __global__ void __launch_bounds__(512) fused_q16_kernel(FusedParams p) {
                 }
             }
         }
+        STAMP(13);
     }  // macro-tile loop
   }  // segments
+#ifdef NIC_STAMPS
+    if (lane == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 8 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
+#pragma unroll
+        for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
 
     // ---------------- one record per workgroup
     float* rec = p.partials + (int64_t)blockIdx.x * S::REC;

@@ -427,7 +427,63 @@ static int encode_impl(const nic_path_desc* d, const float* g0, const float* g1,
     return (int)hipGetLastError();
 }
 
+// stripe exchange (include/nicv2_hip.h: nic_stripe_pack / _unpack): one thread per float of the exchange buffer
+struct RowSets {
+    nic_row_set s[2];
+    int n;
+    int64_t n_small, count[2];
+};
+template <bool PACK>
+__global__ void __launch_bounds__(256) stripe_rows_kernel(float* small_buf, RowSets rs, float* buf) {
+    const int64_t total = rs.n_small + rs.count[0] + rs.count[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float* elem;
+        if (i < rs.n_small) {
+            elem = small_buf + i;
+        } else {
+            int64_t j = i - rs.n_small;
+            const int k = (rs.n > 1 && j >= rs.count[0]) ? 1 : 0;
+            if (k) j -= rs.count[0];
+            const nic_row_set& q = rs.s[k];
+            const int64_t per_c = (int64_t)q.nrows * q.row_elems;
+            const int c = (int)(j / per_c);
+            const int64_t r = j - (int64_t)c * per_c;
+            const int b = (int)(r / q.row_elems), x = (int)(r - (int64_t)b * q.row_elems);
+            elem = q.base + (int64_t)c * q.plane + (int64_t)q.rows[b] * q.row_elems + x;
+        }
+        if (PACK) buf[i] = *elem;
+        else *elem = buf[i];
+    }
+}
+static int stripe_rows(bool pack, float* small_buf, int64_t n_small, const nic_row_set* sets, int nsets, float* buf, void* stream) {
+    if (!buf || (n_small > 0 && !small_buf) || (nsets > 0 && !sets)) return NIC_E_NULL;
+    if (n_small < 0 || nsets < 0 || nsets > 2) return NIC_E_ARG;
+    RowSets rs;
+    rs.n = nsets; rs.n_small = n_small; rs.count[0] = rs.count[1] = 0;
+    for (int k = 0; k < nsets; ++k) {
+        if (!sets[k].base) return NIC_E_NULL;
+        if (sets[k].nrows < 0 || sets[k].nrows > NIC_STRIPE_MAX_ROWS || sets[k].row_elems < 1 || sets[k].channels < 1) return NIC_E_ARG;
+        for (int b = 0; b < sets[k].nrows; ++b)
+            if (sets[k].rows[b] < 0 || (int64_t)(sets[k].rows[b] + 1) * sets[k].row_elems > sets[k].plane) return NIC_E_SHAPE;
+        rs.s[k] = sets[k];
+        rs.count[k] = (int64_t)sets[k].channels * sets[k].nrows * sets[k].row_elems;
+    }
+    const int64_t total = n_small + rs.count[0] + rs.count[1];
+    if (total == 0) return NIC_OK;
+    const dim3 g(blocks_for(total)), b(256);
+    if (pack) hipLaunchKernelGGL(stripe_rows_kernel<true>, g, b, 0, (hipStream_t)stream, small_buf, rs, buf);
+    else hipLaunchKernelGGL(stripe_rows_kernel<false>, g, b, 0, (hipStream_t)stream, small_buf, rs, buf);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
+
+int nic_stripe_pack(const float* small_buf, int64_t n_small, const nic_row_set* sets, int nsets, float* buf, void* stream) {
+    return stripe_rows(true, const_cast<float*>(small_buf), n_small, sets, nsets, buf, stream);
+}
+int nic_stripe_unpack(float* small_buf, int64_t n_small, const nic_row_set* sets, int nsets, const float* buf, void* stream) {
+    return stripe_rows(false, small_buf, n_small, sets, nsets, const_cast<float*>(buf), stream);
+}
 
 int nic_abi_version(void) { return NIC_ABI_VERSION; }
 

@@ -162,12 +162,48 @@ def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
+def _row_set(plan: StripePlan, level: int, grad: torch.Tensor):
+    """nic_row_set of a grid-gradient tensor [C, rows, ...]: the stripe axis is tensor axis 1, a node row = everything behind it"""
+    from . import _lib
+    rows = plan.boundary_rows(level)
+    if len(rows) > _lib.NIC_STRIPE_MAX_ROWS:
+        raise ValueError(f"{len(rows)} stripe boundaries: the exchange kernels take at most {_lib.NIC_STRIPE_MAX_ROWS}")
+    rs = _lib.NicRowSet()
+    rs.base = grad.data_ptr()
+    rs.plane = int(grad[0].numel())
+    rs.row_elems = int(grad[0, 0].numel())
+    rs.channels = int(grad.shape[0])
+    rs.nrows = len(rows)
+    for i, r in enumerate(rows):
+        rs.rows[i] = int(r)
+    return rs
+
+
 def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor, grad_g1: torch.Tensor, group=None,
                     reduce: Optional[Callable] = None) -> None:
     """The exchange step of a stripe-sharded training step, in place: ``small`` (loss + decoder gradients, a 1-D view of the flat
     bucket) and the boundary node rows of the two grid gradients become sums over ranks - ONE all-reduce of
-    ``small.numel() + (world - 1) * C * (row of G0 + row of G1)`` floats."""
+    ``small.numel() + (world - 1) * C * (row of G0 + row of G1)`` floats.  On the device the buffer is packed and unpacked by one
+    launch each (``nic_stripe_pack`` / ``nic_stripe_unpack``); CPU tensors (the gloo tests with the oracle as step function) take the
+    torch formulation below."""
     if plan.world == 1:
+        return
+    if grad_g0.is_cuda and grad_g0.is_contiguous() and grad_g1.is_contiguous() and small.is_contiguous():
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        key = ("xbuf", str(grad_g0.device), grad_g0.data_ptr(), grad_g1.data_ptr())
+        cached = plan._index.get(key)
+        if cached is None:
+            sets = (_lib.NicRowSet * 2)(_row_set(plan, 0, grad_g0), _row_set(plan, 1, grad_g1))
+            n = small.numel() + sum(int(q.channels) * int(q.nrows) * int(q.row_elems) for q in sets)
+            cached = plan._index[key] = (sets, torch.empty(n, dtype=torch.float32, device=grad_g0.device))
+        sets, buf = cached
+        with torch.cuda.device(grad_g0.device):
+            st = _lib.stream_ptr(grad_g0.device)
+            _lib.check(lib.nic_stripe_pack(_lib.ptr(small), small.numel(), sets, 2, _lib.ptr(buf), st), "nic_stripe_pack")
+            (reduce or _all_reduce_sum)(buf, group)
+            _lib.check(lib.nic_stripe_unpack(_lib.ptr(small), small.numel(), sets, 2, _lib.ptr(buf), st), "nic_stripe_unpack")
         return
     idx0, idx1 = plan.boundary_index(grad_g0.device)
     h0, h1 = grad_g0.index_select(1, idx0), grad_g1.index_select(1, idx1)
@@ -177,6 +213,22 @@ def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor
     small.copy_(buf[:ns].view_as(small))
     grad_g0.index_copy_(1, idx0, buf[ns:ns + n0].view_as(h0))
     grad_g1.index_copy_(1, idx1, buf[ns + n0:].view_as(h1))
+
+
+def stripe_param_blocks(plan: StripePlan, level: int, *tensors: torch.Tensor) -> List[Tuple[torch.Tensor, ...]]:
+    """Optimiser sharding: the node rows of grid ``level`` this rank's samples touch (its stripe incl. the boundary row on either side),
+    as one contiguous block per channel of every given tensor of the grid's shape ``[C, rows, ...]`` (parameter, gradient, 16-bit
+    mirror).  A rank runs Adam over these blocks ONLY - 1 / world of the optimiser work, moments allocated for them only
+    (``stripe_state``) - so nothing outside its stripe ever moves, whatever state a resumed run starts from (round 2 ran Adam over
+    the whole tensors and relied on zero gradients AND zero moments outside the stripe)."""
+    lo, hi = plan.node_rows(level)
+    return [tuple(t[c, lo:hi + 1] for t in tensors) for c in range(tensors[0].shape[0])]
+
+
+def stripe_state(plan: StripePlan, level: int, grid: torch.Tensor) -> torch.Tensor:
+    """zero Adam moments for this rank's node rows of ``grid``: ``[C, own rows, ...]`` (channel c = the block of stripe_param_blocks)"""
+    lo, hi = plan.node_rows(level)
+    return torch.zeros((grid.shape[0], hi - lo + 1) + tuple(grid.shape[2:]), dtype=torch.float32, device=grid.device)
 
 
 def assemble_stripes(plan: StripePlan, g0: torch.Tensor, g1: torch.Tensor, group=None) -> None:

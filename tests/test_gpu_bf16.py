@@ -174,3 +174,193 @@ def test_plain_bf16_image_targets_and_dy(dev):
         grads = torch.autograd.grad(y, params, dy)
         for a, b in zip(grads, base.grad_mlp):
             assert relmax(a, b) <= 1e-5, "dY entry point"
+
+
+def _emulated_y(x, mlp):
+    """forward of the precision-emulating oracle alone"""
+    return O.mlp_forward_backward_bf16(x, mlp, torch.zeros(x.shape[0], 3), x.shape[0])[0]
+
+
+NORTH_STAR_4K = [
+    # n_linear, grid storage, products
+    (5, torch.bfloat16, "bf16"),          # BASELINE configs[1] as literally stated: "4 x 64" decoder, bf16 grids, bf16 arithmetic (bench.py: roofline_4x64)
+    (5, torch.bfloat16, "split"),         # the same decoder and storage on the split-bf16 kernel (fused_mlpn)
+    (5, torch.float32, "split"),
+    (3, torch.bfloat16, "bf16"),
+    (3, torch.float32, "bf16"),           # bench.py: roofline_bf16
+]
+
+
+@pytest.mark.parametrize("nl,gdt,prec", NORTH_STAR_4K, ids=lambda v: str(v).replace("torch.", ""))
+def test_full_size_4k_north_star_variants(dev, nl, gdt, prec):
+    """BASELINE config 2 at 3840 x 2160 in the variants the north star names (5-Linear decoder, 16-bit grid storage, bf16 products) -
+    VERDICT r02 'configs_untested'.  Too big for the oracle end to end, so, like test_full_size_4k_properties:
+    (a) random 16 x 16 windows against the oracle sample for sample (the emulating oracle for the plain-bf16 products; in-kernel noise by
+        global sample id; 16-bit grids: the oracle works on the widened values),
+    (b) the loss equals an independent reduction of the kernel's own y,
+    (c) two passes in one launch == the image listed twice (what a rank of a 2-GPU weak-scaling step runs),
+    (d) run to run: loss and decoder gradients bit-stable,
+    (e) a rank's stripe of an 8-GPU step (2160 x 480, 8 passes, global sample ids): nothing outside its node rows is touched, and the
+        plain-bf16 step agrees with the split step at bf16 precision."""
+    from neural_image_compression_v2_amd import _lib, fused
+    H, W = 2160, 3840
+    g = torch.Generator().manual_seed(21)
+    fp, _ = O.create_pyramid((H // 4, W // 4), 12, 8, dim=2, no_mip=True, generator=g)
+    g0, g1 = fp[0].detach().to(gdt), fp[1].detach().to(gdt)
+    g0w, g1w = g0.float(), g1.float()
+    mlp = O.init_mlp(73, 64, generator=g, n_linear=nl)
+    params = [q.to(dev) for q in mlp.tensors()]
+    g0d, g1d = g0.to(dev), g1.to(dev)
+    N = H * W
+    target = torch.rand(N, 3, generator=g).to(dev)
+    AL = _lib.NIC_FLAG_ORIGINS_ALIGNED
+    pk = dict(split_bf16=prec == "split", bf16=prec == "bf16")
+    kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=3, flags=AL, **pk)
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, **kw)
+    out = fused.fused_forward_backward(geo, g0d, g1d, [(0, 0)], params, target, want_y=True)
+    assert out.grad_g0.dtype == torch.float32 and tuple(out.grad_g0.shape) == (12, 961, 541)
+    # (a)
+    rs = np.random.RandomState(0)
+    worst = 0.0
+    for _ in range(48):
+        ox, oy = int(rs.randint(0, H - 16)), int(rs.randint(0, W - 16))
+        ix = torch.arange(ox, ox + 16).repeat_interleave(16)
+        iy = torch.arange(oy, oy + 16).repeat(16)
+        rows = (ix * W + iy)[::37]
+        noise = torch.stack([O.kernel_noise(1, 73, 8, seed=7, offset=3, sample_base=int(r))[0] for r in rows])
+        x = O.create_decoder_input(g0w, g1w, [(ox, oy)], (16, 16), 0.25, 0, 6)[::37]
+        yr = _emulated_y(x + noise, mlp) if prec == "bf16" else O.mlp_forward(x + noise, mlp)
+        worst = max(worst, float((out.y[rows.to(dev)].cpu() - yr).abs().max()))
+    assert worst <= (2e-3 if prec == "bf16" else 5e-6), f"window rows: {worst:.2e}"
+    # (b)
+    loss_ind = ((out.y.double() - target.double()) ** 2).mean()
+    assert abs(float(out.loss) - float(loss_ind)) <= 1e-5 * float(loss_ind)
+    # (c)
+    tgt2 = torch.cat([target, target.flip(0)])
+    pa = fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, passes=2, **kw),
+                                      g0d, g1d, [(0, 0)], params, tgt2)
+    pb = fused.fused_forward_backward(fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=2, **kw),
+                                      g0d, g1d, [(0, 0), (0, 0)], params, tgt2)
+    assert relmax(pa.loss, pb.loss) <= 1e-5
+    for a, b in zip([pa.grad_g0, pa.grad_g1] + pa.grad_mlp, [pb.grad_g0, pb.grad_g1] + pb.grad_mlp):
+        assert relmax(a, b) <= 1e-4, "passes == crops listed twice"
+    # (d)
+    again = fused.fused_forward_backward(geo, g0d, g1d, [(0, 0)], params, target)
+    assert torch.equal(again.loss, out.loss)
+    for a, b in zip(again.grad_mlp, out.grad_mlp):
+        assert torch.equal(a, b), "decoder gradients are bit-stable run to run"
+    del out, pa, pb, tgt2, again
+    # (e)
+    sw, world = 480, 8
+    tgt_s = target.view(H, W, 3)[:, 1920:1920 + sw].reshape(-1, 3).repeat(world, 1).contiguous()
+    res = {}
+    for mode in ({prec, "split"}):
+        gs = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, sw), num_crops=1, passes=world,
+                                noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=11, sample_base=H * 1920 * world,
+                                loss_scale=1.0 / (3.0 * H * W * world), flags=AL, split_bf16=mode == "split", bf16=mode == "bf16")
+        res[mode] = fused.fused_forward_backward(gs, g0d, g1d, [(0, 1920)], params, tgt_s)
+    r = res[prec]
+    lo, hi = 1920 // 4, (1920 + sw) // 4
+    assert float(r.grad_g0[:, :lo].abs().sum()) == 0.0 and float(r.grad_g0[:, hi + 1:].abs().sum()) == 0.0 and float(r.grad_g0[:, lo:hi + 1].abs().sum()) > 0.0
+    if prec == "bf16":
+        s = res["split"]
+        assert relmax(r.loss, s.loss) <= 1e-3
+        for a, b in zip([r.grad_g0, r.grad_g1] + r.grad_mlp, [s.grad_g0, s.grad_g1] + s.grad_mlp):
+            assert relmax(a, b) <= 3e-2, "plain bf16 against split products"
+
+
+@pytest.mark.parametrize("method", [4, 3])
+def test_full_size_video_slab_plain_bf16(dev, method):
+    """BASELINE config 4 at full size on the plain-bf16 quarter kernels (the north star's arithmetic for the video field), one rank's slab
+    z in [720, 960) of the 1920 x 1080 x 64 field, bf16 grid storage: windows against the emulating oracle, independent loss, nothing
+    outside the slab's node planes touched, run to run; and the step against the chained-split kernels at bf16 precision."""
+    from neural_image_compression_v2_amd import _lib, fused
+    T, HH, WW, z0, zs = 64, 1080, 1920, 720, 240
+    g = torch.Generator().manual_seed(31)
+    g0 = (torch.rand(12, WW // 4 + 1, HH // 4 + 1, T // 4 + 1, generator=g) - 0.498).to(torch.bfloat16)
+    g1 = (torch.rand(12, WW // 8 + 1, HH // 8 + 1, T // 8 + 1, generator=g) - 0.498).to(torch.bfloat16)
+    cin = O.decoder_input_channels(12, 6, 3, method)
+    mlp = O.init_mlp(cin, 64, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    g0d, g1d = g0.to(dev), g1.to(dev)
+    ext = (T, HH, zs)
+    n = T * HH * zs
+    n_glob = T * HH * WW
+    base = 3 * n
+    target = torch.rand(n, 3, generator=g).to(dev)
+    kw = dict(dim=3, method=method, step_number=0.25, mip_level=0, extent=ext, num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5,
+              noise_offset=2, sample_base=base, loss_scale=1.0 / (3.0 * n_glob), flags=_lib.NIC_FLAG_ORIGINS_ALIGNED)
+    org = [(0, 0, z0)]
+    out = fused.fused_forward_backward(fused.PathGeometry(bf16=True, **kw), g0d, g1d, org, params, target, want_y=True)
+    rs = np.random.RandomState(1)
+    tri = method == 3
+    worst = 0.0
+    for _ in range(32):
+        ox, oy, oz = int(rs.randint(0, T - 4)), int(rs.randint(0, HH - 4)), int(rs.randint(0, zs - 4))
+        idx = torch.tensor([((ox + a) * HH + (oy + b)) * zs + (oz + c) for a in range(4) for b in range(4) for c in range(4)])
+        x = O.create_decoder_input(g0.float(), g1.float(), [(ox, oy, z0 + oz)], (4, 4, 4), 0.25, 0, 6, method=method, use_tri_pe=tri)
+        noise = torch.stack([O.kernel_noise(1, cin, 8, seed=5, offset=2, sample_base=base + int(r), quarter=True)[0] for r in idx])
+        worst = max(worst, float((out.y[idx.to(dev)].cpu() - _emulated_y(x + noise, mlp)).abs().max()))
+    assert worst <= 2e-3, f"window rows: {worst:.2e}"
+    loss_ind = ((out.y.double() - target.double()) ** 2).sum() / (3.0 * n_glob)
+    assert abs(float(out.loss) - float(loss_ind)) <= 1e-5 * float(loss_ind)
+    lo0, hi0 = z0 // 4, (z0 + zs) // 4
+    assert float(out.grad_g0[:, :lo0].abs().sum()) == 0.0 and float(out.grad_g0[:, hi0 + 1:].abs().sum()) == 0.0
+    assert float(out.grad_g1[:, :z0 // 8].abs().sum()) == 0.0 and float(out.grad_g1[:, (z0 + zs) // 8 + 1:].abs().sum()) == 0.0
+    assert float(out.grad_g0[:, lo0:hi0 + 1].abs().sum()) > 0.0
+    again = fused.fused_forward_backward(fused.PathGeometry(bf16=True, **kw), g0d, g1d, org, params, target)
+    assert torch.equal(again.loss, out.loss)
+    for p_, q_ in zip(again.grad_mlp, out.grad_mlp):
+        assert torch.equal(p_, q_), "decoder gradients are bit-stable run to run"
+    # against the chained-split kernels on the widened grids (their in-kernel noise is numbered differently: compare without noise)
+    kq = dict(kw, noise_mode=_lib.NIC_NOISE_NONE)
+    a = fused.fused_forward_backward(fused.PathGeometry(bf16=True, **kq), g0d, g1d, org, params, target)
+    b = fused.fused_forward_backward(fused.PathGeometry(split_bf16=True, **kq), g0d.float(), g1d.float(), org, params, target)
+    assert relmax(a.loss, b.loss) <= 1e-3
+    for p_, q_ in zip([a.grad_g0, a.grad_g1] + a.grad_mlp, [b.grad_g0, b.grad_g1] + b.grad_mlp):
+        assert relmax(p_, q_) <= 3e-2, "plain bf16 against split products"
+
+
+def test_stripe_exchange_kernels_and_loss_history_wrap(dev):
+    """(1) nic_stripe_pack / nic_stripe_unpack (the per-step exchange buffer of the stripe-sharded step) against the torch formulation, 2D and
+    3D row sets; (2) ADVICE r02: StepPlan's loss slots - a history longer than LOSS_SLOTS stays correct (the plan moves to a fresh buffer)."""
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.distributed import plan_stripes, stripe_exchange
+    g = torch.Generator().manual_seed(1)
+    for shape0, shape1, L in (((12, 97, 33), (12, 49, 17), 384), ((12, 49, 9, 5), (12, 25, 5, 3), 192)):
+        plan = plan_stripes(L, 8, 1, 4)
+        gg0, gg1 = torch.rand(*shape0, generator=g).to(dev), torch.rand(*shape1, generator=g).to(dev)
+        small = torch.rand(1000, generator=g).to(dev)
+        ref0, ref1, refs = gg0.clone(), gg1.clone(), small.clone()
+        seen = {}
+
+        def fake_reduce(buf, group):                                       # "sum over 3 ranks with identical data"
+            seen["n"] = buf.numel()
+            buf.mul_(3.0)
+        stripe_exchange(plan, small, gg0, gg1, reduce=fake_reduce)
+        idx0, idx1 = plan.boundary_index(dev)
+        ref0[:, idx0] *= 3.0
+        ref1[:, idx1] *= 3.0
+        assert seen["n"] == 1000 + 3 * 12 * (ref0[0, 0].numel() + ref1[0, 0].numel())
+        assert torch.equal(gg0, ref0) and torch.equal(gg1, ref1) and torch.equal(small, refs * 3.0)
+    # (2)
+    fp, _ = _pyramid(2, 16, 12, seed=4, no_mip=True)
+    g0, g1 = fp[0].to(dev), fp[1].to(dev)
+    mlp = O.init_mlp(73, 64, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    img = torch.randint(0, 256, (3, 64, 64), generator=g, dtype=torch.uint8).to(dev)
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(16, 16), num_crops=2, split_bf16=True)
+    old = fused.StepPlan.LOSS_SLOTS
+    fused.StepPlan.LOSS_SLOTS = 4
+    try:
+        plan = fused.StepPlan(geo, g0, g1, params, fused.TargetImage(img))
+        hist, want = [], []
+        for i in range(11):
+            org = [(i, 2 * i), (3 * i, i)]
+            hist.append(plan.run(org, _lib.NIC_NOISE_NONE, 0, i).loss)
+            want.append(float(fused.fused_forward_backward(geo, g0, g1, org, params, fused.TargetImage(img)).loss))
+        got = torch.stack(hist).cpu().tolist()
+        # (the plan launches without the origins-aligned flag: another tiling, the same sums up to fp32 summation order)
+        assert len(set(want)) == 11 and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(got, want)), (got, want)
+    finally:
+        fused.StepPlan.LOSS_SLOTS = old

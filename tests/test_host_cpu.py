@@ -226,7 +226,7 @@ def _oracle_step(geo, g0, g1, org, params, target, **kw):
     from neural_image_compression_v2_amd import fused
     from oracle import nic_oracle as O
     mlp = O.MLPParams([params[0], params[2], params[4]], [params[1], params[3], params[5]])
-    noise = O.kernel_noise(geo.n_samples, geo.cin, geo.num_bits, geo.noise_seed, geo.noise_offset, geo.sample_base)
+    noise = None if geo.noise_mode == 0 else O.kernel_noise(geo.n_samples, geo.cin, geo.num_bits, geo.noise_seed, geo.noise_offset, geo.sample_base)
     r = O.forward_backward(g0, g1, mlp, [tuple(int(v) for v in o) for o in org], geo.extent, geo.step_number, geo.mip_level, target, noise,
                            geo.pe_channels, method=geo.method, use_tri_pe=geo.use_tri_pe, mean_over=(geo.n_samples if geo.loss_scale is None else int(round(1 / (3 * geo.loss_scale)))))
     offs, sizes, total = fused.grad_bucket_layout(geo, g0, g1)
@@ -398,11 +398,107 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert len(lines) == 1, r.stdout
     import json
     rec = json.loads(lines[0])
-    assert rec == {"launch_check": True, "n_gpus": 2, "rank_sum": 1.0}
+    assert rec["launch_check"] is True and rec["n_gpus"] == 2 and rec["rank_sum"] == 1.0
+    assert rec["stripes"] == [[0, 1920], [1920, 1920]] and rec["covered"] == 3840          # the 4K image's last sample axis, tiled by the two ranks
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert r2.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r2.stderr
+
+
+@pytest.mark.parametrize("extra,key,want", [
+    (["--workload", "video", "--scaling", "strong"], "stripes", [[0, 640], [640, 640], [1280, 640]]),
+    (["--workload", "video"], "covered", 1920),
+    (["--workload", "fits64"], "fits_per_rank", [21, 21, 22]),
+    (["--scaling", "strong", "--shard", "replicated"], "covered", 3840),
+])
+def test_bench_multi_gpu_workloads_launch(extra, key, want):
+    """every BASELINE multi-GPU configuration has a runnable N-rank command: --workload video / fits64 with --gpus N and
+    the strong-scaling modes of the headline; --launch-check keeps the GPU out of it and prints the per-rank plan"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"] + extra, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 3 and rec["rank_sum"] == 3.0 and rec[key] == want, rec
+
+
+def _video_stripe_worker(rank, world, port, out_path):
+    """3D field, z-stripes, STRONG scaling (one pass over the field split over the ranks), Adam over the rank's own node rows only"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from neural_image_compression_v2_amd import _lib, fused
+        from neural_image_compression_v2_amd.distributed import assemble_stripes, plan_stripes, stripe_exchange, stripe_param_blocks, stripe_state
+        from oracle import nic_oracle as O
+        torch.set_num_threads(2)
+        ext = (8, 8, 32)                                             # sample axes (x, y, z); z is the stripe axis (tensor axis 1 of [C, Z, Y, X])
+        g = torch.Generator().manual_seed(4)
+        fp, _ = O.create_pyramid(tuple(e // 4 for e in ext), 12, 8, dim=3, no_mip=True, generator=g)     # [12, 9, 3, 3], [12, 5, 2, 2]
+        g0, g1 = fp[0].detach().clone(), fp[1].detach().clone()
+        mlp = O.init_mlp(79, 64, generator=g)
+        field = torch.rand(*ext, 3, generator=g)
+        plan = plan_stripes(ext[2], 8, rank, world)
+        n_global = ext[0] * ext[1] * ext[2]                          # strong scaling: every voxel once per step over the whole job
+
+        def geo_of(extent, base, noise=_lib.NIC_NOISE_KERNEL):
+            return fused.PathGeometry(dim=3, method=4, step_number=0.25, mip_level=0, extent=extent, num_crops=1,
+                                      noise_mode=noise, noise_seed=5, noise_offset=2, sample_base=base, loss_scale=1.0 / (3.0 * n_global))
+        local = (ext[0], ext[1], plan.size)
+        tgt = field[:, :, plan.start:plan.start + plan.size].reshape(-1, 3)
+        out = _oracle_step(geo_of(local, ext[0] * ext[1] * plan.start), g0, g1, torch.tensor([[0, 0, plan.start]]), mlp.tensors(), tgt)
+        offs, sizes, _ = fused.grad_bucket_layout(geo_of(local, 0), g0, g1)
+        stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)
+        # "Adam" stand-in with state: p -= 0.5 * (grad + m), moments start NON-ZERO outside the stripe too - only the own rows may move
+        moved = []
+        for level, (p, gr) in enumerate(((g0, out.grad_g0), (g1, out.grad_g1))):
+            before = p.clone()
+            m = stripe_state(plan, level, p) + 0.25                  # a resumed state: non-zero moments
+            for c, (pb, gb) in enumerate(stripe_param_blocks(plan, level, p, gr)):
+                assert pb.is_contiguous() and gb.is_contiguous() and pb.shape == m[c].shape
+                pb -= 0.5 * (gb + m[c])
+            lo, hi = plan.node_rows(level)
+            moved.append(float((p - before)[:, :lo].abs().sum() + (p - before)[:, hi + 1:].abs().sum()))
+        assemble_stripes(plan, g0, g1)
+        # single process: the same voxels as the ranks' stripes in rank order, global sample ids
+        plans = [plan_stripes(ext[2], 8, r, world) for r in range(world)]
+        singles = [_oracle_step(geo_of((ext[0], ext[1], q.size), ext[0] * ext[1] * q.start), fp[0].detach(), fp[1].detach(),
+                                torch.tensor([[0, 0, q.start]]), mlp.tensors(), field[:, :, q.start:q.start + q.size].reshape(-1, 3)) for q in plans]
+        sflat = sum(sg.flat for sg in singles)
+        sg0, sg1 = sum(sg.grad_g0 for sg in singles), sum(sg.grad_g1 for sg in singles)
+        # without noise (its draws are keyed by the sample id, and a stripe numbers its samples on its own extent) the stripes of one pass
+        # ARE the whole-field pass: losses and gradients add up to the single whole-field step
+        quiet = [_oracle_step(geo_of((ext[0], ext[1], q.size), 0, _lib.NIC_NOISE_NONE), fp[0].detach(), fp[1].detach(),
+                              torch.tensor([[0, 0, q.start]]), mlp.tensors(), field[:, :, q.start:q.start + q.size].reshape(-1, 3)) for q in plans]
+        sflat_q, sg0_q = sum(sg.flat for sg in quiet), sum(sg.grad_g0 for sg in quiet)
+        whole = _oracle_step(geo_of(ext, 0, _lib.NIC_NOISE_NONE), fp[0].detach(), fp[1].detach(), torch.tensor([[0, 0, 0]]), mlp.tensors(), field.reshape(-1, 3))
+        res = {"small": float((out.flat[:offs[7]] - sflat[:offs[7]]).abs().max() / sflat[:offs[7]].abs().max()),
+               "moved_outside": max(moved),
+               "p0": float((g0 - (fp[0].detach() - 0.5 * (sg0 + 0.25))).abs().max()), "p1": float((g1 - (fp[1].detach() - 0.5 * (sg1 + 0.25))).abs().max()),
+               # the stripes' sample ids tile the single whole-field pass: same loss, same gradients (the noise is keyed by the global id)
+               "whole_loss": float((sflat_q[0] - whole.flat[0]).abs() / whole.flat[0].abs()), "whole_g0": float((sg0_q - whole.grad_g0).abs().max() / whole.grad_g0.abs().max())}
+        torch.save(res, out_path + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_video_stripes_strong_scaling_and_stripe_owned_adam_gloo():
+    """BASELINE config 4's shape at reduced size over 2 gloo ranks: z-stripes of a 3D field (method 4), STRONG scaling - the stripes of one
+    whole-field pass -, the small exchange, an optimiser update restricted to the rank's own node rows (non-zero moments elsewhere must not
+    move anything: the resume case round 2 documented as broken), assembled grids == the single-process update; and - noise off - the stripes'
+    losses / gradients add up to the whole-field single-process step."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.pt")
+        mp.spawn(_video_stripe_worker, args=(2, port, out), nprocs=2, join=True)
+        for r in range(2):
+            res = torch.load(out + f".{r}")
+            assert res["moved_outside"] == 0.0, res
+            assert res["small"] < 1e-6 and res["p0"] < 1e-6 and res["p1"] < 1e-6, (r, res)
+            assert res["whole_loss"] < 1e-6 and res["whole_g0"] < 1e-5, (r, res)
 
 
 def test_counter_based_sampler_host_functions_match_the_oracle(lib):
