@@ -118,6 +118,8 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "traffic": None, "kernel_ms": round(km, 4), "stats": _pct(kms), "bytes_per_sample": byt, "flop_per_sample": flop,
                          "samples_per_launch": n,
+                         **({"note": "above 1: SURVEY 8d's byte count assumes no reuse at all; neighbouring samples share their corners (64 samples per G0 cell), "
+                                     "the grids sit in L2 / Infinity Cache and the kernel no longer pays those bytes - the figure stops being a bound here"} if gbs > PEAK_HBM_GBS else {}),
                          "mfma_f32_equivalent": {"achieved": round(tfl, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                                  "frac": round(tfl / PEAK_FP32_MATRIX_TFLOPS, 4)}}}
 

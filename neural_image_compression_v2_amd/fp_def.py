@@ -44,8 +44,13 @@ def _q_range(num_bits):
 
 
 def _create(base, dim, channels, num_bits, device, dtype, no_mip):
-    if dtype not in (None, torch.float32):
-        raise NotImplementedError("fp32 grids only")
+    """``dtype`` float32: the reference's fp32 leaves.  float16 (what the reference's MLP_NUM_DTYPE = 16 maps its grids to, utils.py:301-313;
+    its own 16-bit run does not train, readme.md:9) or bfloat16: 16-bit grid STORAGE - every returned leaf is the fp32 MASTER the optimiser
+    updates (same init expression, rounded to the storage type so that master == stored value at the start) and carries the 16-bit tensor
+    the kernels gather from as ``leaf.mirror16``; the fused entry points pick the mirror up by themselves (fused.grid_storage),
+    ``optim.FusedAdam.set_mirror`` keeps it in step with the master."""
+    if dtype not in (None, torch.float32, torch.float16, torch.bfloat16):
+        raise NotImplementedError("grids are fp32, or float16 / bfloat16 storage with fp32 masters")
     base = (int(base),) * dim if isinstance(base, int) else tuple(int(b) for b in base)
     if len(base) != dim:
         raise ValueError("one base size per axis")
@@ -55,7 +60,14 @@ def _create(base, dim, channels, num_bits, device, dtype, no_mip):
     for i in range(levels * 2):
         shape = [channels] + [b // (2 ** i) + 1 for b in reversed(base)]     # tensor axes (z,) y, x
         # the reference's own expression (fp_def.py:54,76): same RNG stream and rounding as it for a given seed / device
-        g = ((hi - lo) * torch.rand(*shape, device=device, dtype=torch.float32) + lo).requires_grad_(True)
+        g = (hi - lo) * torch.rand(*shape, device=device, dtype=torch.float32) + lo
+        if dtype in (torch.float16, torch.bfloat16):
+            mirror = g.to(dtype)
+            g = mirror.to(torch.float32)
+            g.requires_grad_(True)
+            g.mirror16 = mirror
+        else:
+            g.requires_grad_(True)
         pyramid.append(g)
     return pyramid, levels
 

@@ -159,6 +159,13 @@ class PathGeometry:
         return d
 
 
+def grid_storage(g: torch.Tensor) -> torch.Tensor:
+    """the tensor the kernels gather from: the 16-bit mirror of an fp32 master created by ``create_pyramid(dtype=float16 | bfloat16)``
+    (``master.mirror16``), otherwise the tensor itself"""
+    m = getattr(g, "mirror16", None)
+    return g if m is None else m
+
+
 def check_grids(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor) -> None:
     for name, g in (("G0", g0), ("G1", g1)):
         if g.dim() != geo.dim + 1 or g.shape[0] != geo.channels:
@@ -277,8 +284,8 @@ def encode_split(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, coord) -
 @_on_tensor_device
 def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[N, 3]: encode (+ noise) + decoder in one kernel (decode_image's inner step, image_compression.py:313-345)"""
-    g0 = _lib.require_cuda_grid(g0.detach(), "G0")
-    g1 = _lib.require_cuda_grid(g1.detach(), "G1")
+    g0 = _lib.require_cuda_grid(grid_storage(g0).detach(), "G0")
+    g1 = _lib.require_cuda_grid(grid_storage(g1).detach(), "G1")
     check_grids(geo, g0, g1)
     params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
     org = upload_origins(geo, coord, g0.device, g0, g1)
@@ -396,8 +403,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     image_compression.py:239-265.  Gradients are returned, not accumulated into .grad.  Grids may be bfloat16 / float16 STORAGE (2D,
     split_bf16): gathered values are widened to fp32, the returned grid gradients are fp32 tensors of the grids' shapes (feed them to
     ``optim.FusedAdam`` on fp32 masters with ``set_mirror``)."""
-    g0 = _lib.require_cuda_grid(g0.detach(), "G0")
-    g1 = _lib.require_cuda_grid(g1.detach(), "G1")
+    g0 = _lib.require_cuda_grid(grid_storage(g0).detach(), "G0")
+    g1 = _lib.require_cuda_grid(grid_storage(g1).detach(), "G1")
     check_grids(geo, g0, g1)
     params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
     org = upload_origins(geo, coord, g0.device, g0, g1)
@@ -462,8 +469,8 @@ class StepPlan:
         if not isinstance(target, TargetImage):
             raise TypeError("StepPlan reads its targets from a resident TargetImage")
         self.geo = geo
-        self.g0 = _lib.require_cuda_grid(g0.detach(), "G0")
-        self.g1 = _lib.require_cuda_grid(g1.detach(), "G1")
+        self.g0 = _lib.require_cuda_grid(grid_storage(g0).detach(), "G0")
+        self.g1 = _lib.require_cuda_grid(grid_storage(g1).detach(), "G1")
         check_grids(geo, self.g0, self.g1)
         self.params = check_mlp([p.detach() for p in params], geo.cin, geo.hidden)
         self.dev = self.g0.device
@@ -500,7 +507,7 @@ class StepPlan:
             self.hi.append(hi)
 
     def matches(self, g0, g1, params, target) -> bool:
-        return (g0.data_ptr() == self.g0.data_ptr() and g1.data_ptr() == self.g1.data_ptr() and target is self.target
+        return (grid_storage(g0).data_ptr() == self.g0.data_ptr() and grid_storage(g1).data_ptr() == self.g1.data_ptr() and target is self.target
                 and len(params) == len(self.params) and all(p.data_ptr() == q.data_ptr() for p, q in zip(params, self.params)))
 
     def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int) -> StepOutput:

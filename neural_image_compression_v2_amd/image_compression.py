@@ -64,21 +64,30 @@ class ImageCompression:
         self.device = torch.device(device) if device is not None else c.DEVICE
         if self.device.type != "cuda":
             raise RuntimeError("ImageCompression needs a HIP device: there is no CPU implementation of this path")
-        if c.MLP_NUM_DTYPE != 32:
-            raise NotImplementedError("MLP_NUM_DTYPE=32 only (the reference's 16-bit path is unfinished, readme.md:9)")
+        if c.MLP_NUM_DTYPE not in (16, 32):
+            raise NotImplementedError("MLP_NUM_DTYPE is 32, or 16 = float16 grid storage (utils.py:301-313 maps 16 to torch.float16; the reference "
+                                      "never casts its decoder, image_compression.py:350, and its own 16-bit run does not train, readme.md:9)")
+        grid_dtype = torch.bfloat16 if c.TF_GRID_BF16 else (torch.float16 if c.MLP_NUM_DTYPE == 16 else torch.float32)
+        if grid_dtype != torch.float32 and c.FP_DIMENSION == 3 and not c.TF_PLAIN_BF16:
+            raise NotImplementedError("16-bit grid storage in 3D runs on the plain-bf16 kernels: set TF_PLAIN_BF16=True")
+        if grid_dtype != torch.float32 and c.FP_DIMENSION == 2 and not (c.TF_SPLIT_BF16 or c.TF_PLAIN_BF16):
+            raise NotImplementedError("16-bit grid storage needs TF_SPLIT_BF16 or TF_PLAIN_BF16")
         if seed is not None:
             torch.manual_seed(seed)
             random.seed(seed)
         self.decoder = ColorDecoder(c.DECODER_INPUT_CHANNELS, c.HIDDEN_LAYER_CHANNELS, c.DECODER_LINEAR_LAYERS).to(self.device)     # :350
         pyr = create_pyramid if c.FP_DIMENSION == 2 else create_pyramid_3d
         self.feature_pyramid, self.feature_pyramid_levels = pyr(c.FEATURE_PYRAMID_SIZE, c.FEATURE_PYRAMID_CHANNELS, c.FP_BITS,
-                                                                 self.device, torch.float32, c.TF_NO_MIP)    # :352-357
+                                                                 self.device, grid_dtype, c.TF_NO_MIP)       # :352-357
         self.feature_pyramid_mip_levels_dict = create_pyramid_mip_levels(c.IMAGE_SIZE, c.FEATURE_PYRAMID_SIZE)  # :360
         # Adam + the grids' clamp in one launch per step (optim.FusedAdam; state layout of torch.optim.Adam)
         self.optimizer = FusedAdam([{"params": self.feature_pyramid, "lr": 0.01},
                                     {"params": self.decoder.parameters(), "lr": 0.005}])                   # :361-364
         self.optimizer.set_clamp(self.feature_pyramid, -(2 ** c.FP_BITS - 1) / 2 ** (c.FP_BITS + 1), 0.5)  # fp_def.py:227-232
         self.optimizer.zero_grad_in_step(self.feature_pyramid)      # the grids' gradient buckets are zeroed by the Adam launch itself
+        for t in self.feature_pyramid:                              # 16-bit storage: the launch that updates a master rewrites its mirror
+            if getattr(t, "mirror16", None) is not None:
+                self.optimizer.set_mirror(t, t.mirror16)
         self.scheduler = CosineAnnealing(self.optimizer, T_max=c.NUM_EPOCHS, eta_min=0)   # :365 (torch's CosineAnnealingLR, bit for bit, without its overhead)
         self.images: List[torch.Tensor] = []
         self.loss_history: List[torch.Tensor] = []
@@ -333,8 +342,11 @@ class ImageCompression:
                 from .fp_def import fp_load
                 fp = fp_load(fp, c.FP_BITS, torch.float32)
                 stored = False
-            run = (lambda geo, org: fused.fused_forward_u8(geo, fp[2 * fl], fp[2 * fl + 1], org, params)) if stored else \
-                  (lambda geo, org: fused.fused_forward(geo, fp[2 * fl], fp[2 * fl + 1], org, params))
+            ga, gb = fp[2 * fl], fp[2 * fl + 1]
+            if D == 3 and not stored:
+                ga, gb = ga.detach(), gb.detach()           # 3D decodes read the fp32 masters (the 16-bit mirrors are a training-side storage; 2D decodes gather from them)
+            run = (lambda geo, org: fused.fused_forward_u8(geo, ga, gb, org, params)) if stored else \
+                  (lambda geo, org: fused.fused_forward(geo, ga, gb, org, params))
             split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)
             if div_slice == 1:
                 y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split), [[0] * D])

@@ -42,6 +42,8 @@ class Settings:
     TF_SPLIT_BF16: bool = True           # not in the reference: fused training steps and decodes run their matrix products as hi + lo bf16
                                          # pairs on the bf16 matrix pipe (2D: all of them, 1.8x; 3D: the chained ones, 1.2x; gradients within
                                          # 5e-6 of the fp32 kernels).  False: fp32 MFMAs throughout
+    TF_GRID_BF16: bool = False           # not in the reference: bfloat16 grid STORAGE with fp32 masters (MLP_NUM_DTYPE = 16 is the reference's own route and
+                                         # maps the grids to float16, utils.py:301-313; this flag selects bfloat16 instead)
     TF_PLAIN_BF16: bool = False          # not in the reference: fused training steps in PLAIN bf16 products (NIC_FLAG_BF16: one bf16 value per operand, fp32
                                          # accumulation; every layout, 3 or 5 Linear layers; 1.5x (2D) / 2.5x (3D) faster than the split products; results
                                          # within ~1e-2 of fp32 arithmetic - BASELINE.json's "bf16").  Decodes stay on the split / fp32 inference kernels

@@ -364,3 +364,41 @@ def test_stripe_exchange_kernels_and_loss_history_wrap(dev):
         assert len(set(want)) == 11 and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(got, want)), (got, want)
     finally:
         fused.StepPlan.LOSS_SLOTS = old
+
+
+@pytest.mark.parametrize("cfgkw", [dict(MLP_NUM_DTYPE=16), dict(TF_GRID_BF16=True, TF_PLAIN_BF16=True),
+                                   dict(IMAGE_DIMENSION=3, COMPRESSION_METHOD=4, IMAGE_SIZE=32, IMAGE_3D_SIZE=32, CROP_MIP_LEVEL=4, TF_GRID_BF16=True, TF_PLAIN_BF16=True)],
+                         ids=["fp16-grids-2d-split", "bf16-grids-2d-bf16", "bf16-grids-3d-m4-bf16"])
+def test_16_bit_grid_route_through_the_reference_flags(dev, cfgkw):
+    """the reference's own 16-bit switch (MLP_NUM_DTYPE = 16 -> torch.float16 grids, utils.py:301-313, image_compression.py:352-357) has a
+    drop-in route: create_pyramid(dtype=float16 | bfloat16) returns fp32 master leaves carrying the 16-bit storage the kernels gather from,
+    the fused step trains them (FusedAdam keeps mirror == round(master)), the loop converges and the decode runs."""
+    import random
+    from neural_image_compression_v2_amd import fp_def
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    fp, _ = fp_def.create_pyramid(16, 12, 8, dev, torch.bfloat16, True)
+    assert fp[0].dtype == torch.float32 and fp[0].requires_grad and fp[0].mirror16.dtype == torch.bfloat16
+    assert torch.equal(fp[0].detach(), fp[0].mirror16.float())
+    cfg = Settings(NUM_EPOCHS=60, TF_NO_MIP=True, **{"IMAGE_SIZE": 256, **cfgkw})      # 2D crops are 256^2 whatever CROP_MIP_LEVEL says (image_compression.py:78, Q2)
+    D = cfg.FP_DIMENSION
+    S = cfg.IMAGE_SIZE
+    u = torch.linspace(0, 1, S)
+    if D == 2:
+        img = torch.stack([0.5 + 0.25 * torch.sin(6.28 * (c + 1) * u)[:, None] * torch.cos(6.28 * (c + 2) * u)[None, :] for c in range(3)])
+    else:
+        img = torch.stack([0.5 + 0.25 * torch.sin(6.28 * (c + 1) * u)[:, None, None] * torch.cos(6.28 * u)[None, :, None] * torch.cos(3.14 * u)[None, None, :] for c in range(3)])
+    ic = ImageCompression(cfg, dev, seed=0)
+    den = 255.0 if D == 2 else 256.0
+    ic.set_images([torch.round(img.clamp(0, 1) * (den - 1)).to(torch.uint8)], den=den)
+    want = torch.float16 if cfgkw.get("MLP_NUM_DTYPE") == 16 else torch.bfloat16
+    assert all(t.mirror16.dtype == want for t in ic.feature_pyramid)
+    torch.manual_seed(1)
+    random.seed(1)
+    p0 = float(ic.psnr(ic.feature_pyramid))
+    fp = ic.train_models(ic.feature_pyramid)
+    losses = torch.stack(ic.loss_history).cpu()
+    assert bool(torch.isfinite(losses).all()) and float(losses[-5:].mean()) < 0.5 * float(losses[:5].mean()), losses
+    for t in ic.feature_pyramid:                                   # the masters moved and the mirrors followed them
+        assert torch.equal(t.mirror16, t.detach().to(want))
+    assert float(ic.psnr(fp)) > p0 + 3.0
