@@ -241,7 +241,8 @@ int nic_rgbx_downsample2(const uint32_t *src_rgbx, int s0, int s1, uint32_t *dst
 /* ---- decode straight from the stored codec (image_compression.py:307-346 after fp_load, fp_def.py:258-263):
  *      the grids are the uint8 tensors fp_savable wrote (models.py:61-64), dequantised in-kernel exactly like load4fp
  *      (models.py:68-71), so the result is bit-identical to nic_load4fp_u8 + nic_fused_forward at a quarter of the grid bytes.
- *      desc->num_bits is the codec's bit depth (1..8); desc->noise_mode must be NIC_NOISE_NONE.
+ *      desc->num_bits is the codec's bit depth (1..8); desc->noise_mode must be NIC_NOISE_NONE.  n_linear 3: every layout; n_linear 5: 2D
+ *      (split-bf16 products, like nic_fused_forward for that depth).
  *      y: fp32 [N,3] and/or y_u8: quantize_to_bit(y) as bytes (models.py:39-40) - at least one. */
 int nic_fused_forward_u8(const nic_path_desc *desc, const uint8_t *g0_u8, const uint8_t *g1_u8, const int32_t *origins,
                          const nic_mlp *mlp, float *y, uint8_t *y_u8, void *stream);

@@ -427,18 +427,25 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
     int rc = check_geometry(d);
     if (rc) return rc;
     if (!g0_u8 || !g1_u8 || !origins || !mlp_ok(mlp) || (!y && !y_u8)) return NIC_E_NULL;
-    if (mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;                 // the stored-codec decode is built for the reference's 3-layer decoder
     if (d->noise_mode != NIC_NOISE_NONE) return NIC_E_ARG;            // decoding never adds noise (image_compression.py:307-346)
     if (d->num_bits < 1 || d->num_bits > 8) return NIC_E_ARG;
-    const FusedInfo fi = info_of(layout);
+    const bool deep = mlp_depth(mlp) != 3;                            // 5-layer decoders: the depth-generic kernel, 2D (grid kind 3 = the codec)
+    if (deep && layout != 1 && layout != 2) return NIC_E_UNSUPPORTED;
+    const FusedInfo fi = deep ? info_mlpn(mlp_depth(mlp)) : info_of(layout);
     FusedParams p = zero_params();
-    fill_encode(p, d, fi, reinterpret_cast<const float*>(g0_u8), reinterpret_cast<const float*>(g1_u8), origins, nullptr, true);
+    fill_encode(p, d, fi, reinterpret_cast<const float*>(g0_u8), reinterpret_cast<const float*>(g1_u8), origins, nullptr, !deep);
     fill_mlp(p, mlp);
-    p.grid_u8 = 1;
     p.dq_sub = (float)((1 << (d->num_bits - 1)) - 1);
     p.dq_den = (float)((1 << d->num_bits) - 1);
     p.dq_rcp = 1.0f / p.dq_den;
     p.y = y; p.y_u8 = y_u8;
+    if (deep) {
+        p.grid_kind = 3;
+        balance_units(p, 1, 4);
+        if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
+        return launch_mlpn(layout, p.n_linear, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 1, 4, d->max_workgroups), (hipStream_t)stream);
+    }
+    p.grid_u8 = 1;
     balance_units(p, 2);
     if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
     return launch(layout, SRC_ENCODE, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 2, 4, d->max_workgroups), (hipStream_t)stream);

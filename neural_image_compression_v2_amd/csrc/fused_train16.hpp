@@ -134,28 +134,34 @@ __device__ __forceinline__ int opaque_i(int v) {
 // per lane that walks the channel planes (the per-plane scalar bases of fused_kernel cost ~60 scalar registers, which this kernel
 // does not have: they were spilled to vector lanes and read back with v_readlane in every round).
 // one grid element at byte offset ob: fp32, or 16-bit storage widened to fp32 (p.grid_kind, launch-uniform)
-__device__ __forceinline__ float grid_load16(const char* base, uint32_t ob, int kind) {
+// kind 3: the stored uint8 codec (save4fp, models.py:61-64), dequantised exactly like load4fp (models.py:68-71; see grid_elem)
+__device__ __forceinline__ float grid_load16(const char* base, uint32_t ob, int kind, const FusedParams& p) {
     if (kind == 0) return *reinterpret_cast<const float*>(base + ob);
+    if (kind == 3) {
+        const float n = (float)*reinterpret_cast<const uint8_t*>(base + ob) - p.dq_sub;
+        const float q = mul_rn(n, p.dq_rcp);
+        return fmaf(fmaf(-q, p.dq_den, n), p.dq_rcp, q);
+    }
     const uint32_t hbits = *reinterpret_cast<const uint16_t*>(base + ob);
     if (kind == 1) return __builtin_bit_cast(float, hbits << 16);                          // bfloat16
     return (float)__builtin_bit_cast(_Float16, (uint16_t)hbits);                            // IEEE half
 }
 __device__ __forceinline__ void gather_cell16(const FusedParams& p, uint32_t off0, uint32_t off1, int g, CellRaw16& raw) {
     const int kind = p.grid_kind;
-    const uint32_t eb = kind == 0 ? 4u : 2u;                      // bytes per stored element
+    const uint32_t eb = kind == 0 ? 4u : (kind == 3 ? 1u : 2u);   // bytes per stored element
     const uint32_t pb0 = (uint32_t)p.g0.plane * eb, pb1 = (uint32_t)p.g1.plane * eb;
     {
         uint32_t ob = (off0 + (uint32_t)p.g0.at(g >> 1, g & 1, 0)) * eb;
         const char* base = reinterpret_cast<const char*>(p.g0.p);
 #pragma unroll
-        for (int c = 0; c < kC; ++c, ob += pb0) raw.g0[c] = grid_load16(base, ob, kind);
+        for (int c = 0; c < kC; ++c, ob += pb0) raw.g0[c] = grid_load16(base, ob, kind, p);
     }
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
         uint32_t ob = (off1 + (uint32_t)p.g1.at(c4 >> 1, c4 & 1, 0)) * eb + (uint32_t)(3 * g) * pb1;
         const char* base = reinterpret_cast<const char*>(p.g1.p);
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc, ob += pb1) raw.g1[c4 * 3 + cc] = grid_load16(base, ob, kind);
+        for (int cc = 0; cc < 3; ++cc, ob += pb1) raw.g1[c4 * 3 + cc] = grid_load16(base, ob, kind, p);
     }
 }
 

@@ -338,7 +338,7 @@ class ImageCompression:
             fl = self.feature_pyramid_mip_levels_dict[mip_level]
             params = arc_decoder.linear_params()
             stored = fp[2 * fl].dtype == torch.uint8
-            if stored and len(params) != 6:                 # the stored-codec kernel is built for 3 layers: dequantise once (fp_load), then decode
+            if stored and len(params) != 6 and D != 2:      # 5-layer decoders decode from the stored codec in 2D; elsewhere dequantise once (fp_load), then decode
                 from .fp_def import fp_load
                 fp = fp_load(fp, c.FP_BITS, torch.float32)
                 stored = False

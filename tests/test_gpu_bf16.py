@@ -402,3 +402,52 @@ def test_16_bit_grid_route_through_the_reference_flags(dev, cfgkw):
     for t in ic.feature_pyramid:                                   # the masters moved and the mirrors followed them
         assert torch.equal(t.mirror16, t.detach().to(want))
     assert float(ic.psnr(fp)) > p0 + 3.0
+
+
+def test_plain_bf16_fit_reaches_the_split_fits_psnr(dev):
+    """SURVEY 7 'precision protocol', end to end: a 300-step fit of a 256^2 image in plain-bf16 products against the same fit in split-bf16
+    products (itself within 0.01 dB of the fp32 oracle loop: test_training_trajectory_and_psnr) - identical crop origins, identical in-kernel
+    noise (the 2D numbering is shared), identical initialisation.  The north star asks for a reconstructed PSNR within 0.01 dB."""
+    import random
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    S = 256
+    u = torch.linspace(0, 1, S)
+    g = torch.Generator().manual_seed(8)
+    img = torch.stack([0.5 + 0.25 * torch.sin(6.28 * (c + 1) * u)[:, None] * torch.cos(6.28 * (c + 2) * u)[None, :] for c in range(3)])
+    img = (img + 0.05 * (torch.rand(3, S, S, generator=g) * 2 - 1)).clamp(0, 1)
+    codes = torch.round(img * 255).to(torch.uint8)
+    res = {}
+    for mode in ("split", "bf16"):
+        cfg = Settings(IMAGE_SIZE=S, NUM_EPOCHS=300, TF_NO_MIP=True, TF_PLAIN_BF16=mode == "bf16")
+        ic = ImageCompression(cfg, dev, seed=0)
+        ic.set_images([codes])
+        torch.manual_seed(1)
+        random.seed(1)
+        fp = ic.train_models(ic.feature_pyramid)
+        res[mode] = (float(ic.psnr(fp)), torch.stack(ic.loss_history).cpu())
+    (ps, ls), (pb, lb) = res["split"], res["bf16"]
+    print(f"\nPSNR after 300 steps: split {ps:.4f} dB, plain bf16 {pb:.4f} dB (difference {pb - ps:+.4f} dB); loss trajectories differ by at most "
+          f"{float(((lb - ls).abs() / ls).max()):.2e} relative")
+    assert abs(pb - ps) <= 0.01, (ps, pb)                          # the north star's bound; measured +0.0004 dB (30.8355 against 30.8359), losses within 8e-4
+    assert float(((lb - ls).abs() / ls).max()) <= 5e-2
+
+
+def test_stored_codec_decode_with_the_deep_decoder(dev):
+    """nic_fused_forward_u8 for n_linear = 5: decoding straight from the uint8 codec == fp_load + the fp32-grid decode,
+    bit for bit (the same kernel, the dequantisation in its gather), and within the split kernel's 5e-6 of the oracle"""
+    from neural_image_compression_v2_amd import fused
+    g = torch.Generator().manual_seed(12)
+    fp, _ = _pyramid(2, 32, 12, seed=6, no_mip=True)
+    mlp = O.init_mlp(73, 64, generator=g, n_linear=5)
+    params = [q.to(dev) for q in mlp.tensors()]
+    for bits in (8, 4):
+        cfp = O.fp_savable([f.clamp(*O.q_range(bits)) for f in fp], bits)
+        deq = O.fp_load(cfp, bits)
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(128, 128), num_crops=1, num_bits=bits, split_bf16=True)
+        y8, q8 = fused.fused_forward_u8(geo, cfp[0].to(dev), cfp[1].to(dev), [(0, 0)], params, out="both")
+        yf = fused.fused_forward(geo, deq[0].to(dev), deq[1].to(dev), [(0, 0)], params)
+        assert torch.equal(y8, yf), "uint8-grid decode == fp_load + fp32-grid decode"
+        ref = O.mlp_forward(O.create_decoder_input(deq[0], deq[1], [(0, 0)], (128, 128), 0.25, 0, 6), mlp)
+        assert relmax(y8, ref) <= 5e-6
+        assert torch.equal(q8.cpu(), O.quantize_to_bit(y8.cpu(), 8).to(torch.uint8))

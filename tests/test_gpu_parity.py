@@ -889,6 +889,35 @@ def test_fused_step_at_the_reference_sweep_bit_depths(dev, bits, split):
         assert_rel(a, b, 1e-4, f"bits {bits}: {nme}")
 
 
+@pytest.mark.parametrize("prec", ["f32", "split", "bf16"])
+@pytest.mark.parametrize("method", [3, 4])
+@pytest.mark.parametrize("bits", [2, 4])
+def test_fused_3d_step_at_the_reference_sweep_bit_depths(dev, bits, method, prec):
+    """the reference's own sweeps (the .bat launchers) vary FP_BITS in 3D: COMPRESSION_METHOD 3 / 4 x FP_BITS 2 / 4 / 8 on 32^3 crops.  The 3D
+    in-kernel noise is numbered differently from 2D's (two streams of 8-bit values in the 32-sample kernels, six-bit fields by quarter in the
+    plain-bf16 kernels): FP_BITS 2 and 4 through every 3D training kernel, noise amplitude 2^-bits, grids in [q_min(bits), 1/2]."""
+    from neural_image_compression_v2_amd import _lib, fused
+    g = torch.Generator().manual_seed(70 + bits + method)
+    fp, _ = O.create_pyramid(16, 12, bits, dim=3, no_mip=True, generator=g)
+    g0, g1 = fp[0].detach(), fp[1].detach()
+    cin = O.decoder_input_channels(12, 6, 3, method)
+    mlp = O.init_mlp(cin, 64, generator=g)
+    origins, extent = [(3, 5, 9), (30, 0, 17)], (32, 32, 32)                 # the sweeps' crop
+    n = len(origins) * 32 ** 3
+    target = torch.rand(n, 3, generator=g)
+    noise = O.kernel_noise(n, cin, bits, seed=17, offset=4, sample_base=50, quarter=prec == "bf16")
+    assert 0.4 / 2 ** bits < float(noise.abs().max()) <= 0.5 / 2 ** bits
+    tri = method == 3
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, 6, method=method, use_tri_pe=tri, emulate="bf16" if prec == "bf16" else None)
+    geo = fused.PathGeometry(dim=3, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), num_bits=bits,
+                             noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=17, noise_offset=4, sample_base=50, split_bf16=prec == "split", bf16=prec == "bf16")
+    out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, [q.to(dev) for q in mlp.tensors()], target.to(dev), want_y=True)
+    ty, tg = (2e-3, 3e-3) if prec == "bf16" else (5e-6, 1e-4)
+    assert relmax(out.y, ref.y) <= ty and relmax(out.loss, ref.loss) <= max(1e-5, ty / 10)
+    for nme, a, b in zip(["G0", "G1", "W1", "b1", "W2", "b2", "W3", "b3"], [out.grad_g0, out.grad_g1] + out.grad_mlp, [ref.grad_g0, ref.grad_g1] + ref.grad_mlp):
+        assert relmax(a, b) <= tg, f"bits {bits} method {method} {prec}: {nme} {relmax(a, b):.2e}"
+
+
 # ------------------------------------------------------------------------------------------------ a1 / a3 / a11 through the product
 def test_product_create_pyramid_matches_the_reference_shapes(dev, golden):
     """a1: the PRODUCT's create_pyramid / create_pyramid_3d (fp_def.py:37-78) - level count, grid shapes, init range, leaf-ness -
