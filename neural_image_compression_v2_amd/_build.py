@@ -16,6 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnicv2_hip.so")
 SOURCES = ["simple_kernels.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip", "fused_t16.hip", "fused_mlpn.hip", "fused_q1.hip", "fused_q2.hip", "fused_q3.hip", "fused_q4.hip"]
+# non-default FEATURE_PYRAMID_CHANNELS / PE_CHANNELS on the plain-bf16 kernels: (layout, C, P), one translation unit each
+SOURCES += [f"fused_qc_{l}_{c}_{p}.hip" for l, c, p in [(1, 4, 6), (1, 8, 6), (1, 16, 6), (1, 12, 4), (1, 12, 8), (2, 4, 6), (2, 8, 6), (2, 16, 6), (2, 12, 4), (2, 12, 8),
+                                                         (3, 4, 6), (3, 8, 6), (4, 4, 6), (4, 8, 6), (4, 16, 6)]]
 HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", "fused_q16.hpp", "fused_q16_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results that vector instructions consume may live in the architectural VGPRs instead of bouncing
 # through v_accvgpr_read / write (split training kernel: 656 -> 423 of them, -0.7 %; fp32 2D 18 -> 0 spills; 3D 170 -> 115 / 135 -> 85)

@@ -19,10 +19,30 @@ int cu_count() {
     return n;
 }
 
+// non-default channel counts (FEATURE_PYRAMID_CHANNELS, PE_CHANNELS: var2.py:68-69) exist on the plain-bf16 kernels (NIC_FLAG_BF16), 3 Linear layers:
+// (layout, C, P) - one translation unit each (fused_qc_*.hip)
+#define NIC_CP_LIST(X)                                                                                                       \
+    X(1, 4, 6) X(1, 8, 6) X(1, 16, 6) X(1, 12, 4) X(1, 12, 8) X(2, 4, 6) X(2, 8, 6) X(2, 16, 6) X(2, 12, 4) X(2, 12, 8)     \
+    X(3, 4, 6) X(3, 8, 6) X(4, 4, 6) X(4, 8, 6) X(4, 16, 6)
+bool cp_default(const nic_path_desc* d) { return d->channels == kC && d->pe_channels == kP; }
+bool cp_listed(int layout, int c, int pch) {
+#define X(L, C, P) if (layout == L && c == C && pch == P) return true;
+    NIC_CP_LIST(X)
+#undef X
+    return false;
+}
 // layout id (see nic_device.hpp) or a negative error
 int pick_layout(const nic_path_desc* d) {
     if (!d) return NIC_E_NULL;
-    if (d->channels != kC || d->pe_channels != kP || d->hidden != kH) return NIC_E_UNSUPPORTED;
+    if (d->hidden != kH) return NIC_E_UNSUPPORTED;                       // HIDDEN_LAYER_CHANNELS: 64 only (every tile shape of the kernels hangs on it)
+    if (!cp_default(d)) {
+        if (!(d->flags & NIC_FLAG_BF16)) return NIC_E_UNSUPPORTED;      // other channel counts: the plain-bf16 kernels
+        int layout = NIC_E_UNSUPPORTED;
+        if (d->dim == 2 && d->method == 1) layout = d->pe_mode == NIC_PE_TRIANGULAR ? 1 : (d->pe_mode == NIC_PE_SINUSOIDAL ? 2 : NIC_E_UNSUPPORTED);
+        else if (d->dim == 3 && d->method == 3 && d->pe_mode == NIC_PE_TRIANGULAR) layout = 3;
+        else if (d->dim == 3 && d->method == 4 && d->pe_mode == NIC_PE_SINUSOIDAL) layout = 4;
+        return (layout > 0 && cp_listed(layout, d->channels, d->pe_channels)) ? layout : NIC_E_UNSUPPORTED;
+    }
     if (d->dim == 2 && d->method == 1) return d->pe_mode == NIC_PE_TRIANGULAR ? 1 : (d->pe_mode == NIC_PE_SINUSOIDAL ? 2 : NIC_E_UNSUPPORTED);
     if (d->dim == 3 && d->method == 3) return d->pe_mode == NIC_PE_TRIANGULAR ? 3 : NIC_E_UNSUPPORTED;   // fp_def.py:169
     if (d->dim == 3 && d->method == 4) return d->pe_mode == NIC_PE_SINUSOIDAL ? 4 : NIC_E_UNSUPPORTED;   // fp_def.py:208
@@ -270,8 +290,26 @@ int q16_rec(int layout, int n_linear) {
         default: return q16_record_floats<4>(n_linear);
     }
 }
-FusedInfo info_q16(int layout, int n_linear) { return FusedInfo{0, q16_rec(layout, n_linear), 16, 1, 1, layout <= 2 ? 73 : (layout == 3 ? 127 : 79), 8}; }
+int q16_rec_cp(int layout, int c, int pch) {
+#define X(L, C, P) if (layout == L && c == C && pch == P) return q16_record_floats_cp<L, C, P>();
+    NIC_CP_LIST(X)
+#undef X
+    return 0;
+}
+FusedInfo info_q16(int layout, int n_linear, const nic_path_desc* d = nullptr) {
+    const int c = d ? d->channels : kC, pch = d ? d->pe_channels : kP;
+    const int cin = layout <= 2 ? 5 * c + 2 * pch + 1 : (layout == 3 ? 9 * c + 19 : 5 * c + 19);
+    const bool def = c == kC && pch == kP;
+    return FusedInfo{0, def ? q16_rec(layout, n_linear) : q16_rec_cp(layout, c, pch), 16, 1, 1, cin, 8};
+}
 int launch_q16_any(int layout, int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s) {
+    if (!cp_default(&p.d)) {
+        if (n_linear != 3) return NIC_E_UNSUPPORTED;
+#define X(L, C, P) if (layout == L && p.d.channels == C && p.d.pe_channels == P) return launch_q16_cp<L, C, P>(mode, p, grid, s);
+        NIC_CP_LIST(X)
+#undef X
+        return NIC_E_UNSUPPORTED;
+    }
     switch (layout) {
         case 1: return launch_q16<1>(n_linear, mode, p, grid, s);
         case 2: return launch_q16<2>(n_linear, mode, p, grid, s);
@@ -279,7 +317,13 @@ int launch_q16_any(int layout, int n_linear, int mode, const FusedParams& p, int
         default: return launch_q16<4>(n_linear, mode, p, grid, s);
     }
 }
-int reduce_q16_any(int layout, int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+int reduce_q16_any(int layout, int n_linear, const nic_path_desc* d, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+    if (!cp_default(d)) {
+#define X(L, C, P) if (layout == L && d->channels == C && d->pe_channels == P) return reduce_q16_cp<L, C, P>(partials, n_rec, g, loss, loss_scale, s);
+        NIC_CP_LIST(X)
+#undef X
+        return NIC_E_UNSUPPORTED;
+    }
     switch (layout) {
         case 1: return reduce_q16<1>(n_linear, partials, n_rec, g, loss, loss_scale, s);
         case 2: return reduce_q16<2>(n_linear, partials, n_rec, g, loss, loss_scale, s);
@@ -318,7 +362,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         if (rc) return rc;
     }
     const bool t16 = !q16 && !mlpn && use_t16(layout, d);
-    const FusedInfo fi = q16 ? info_q16(layout, mlp_depth(mlp)) : (mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout)));
+    if (q16 && !cp_default(d) && mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;
+    const FusedInfo fi = q16 ? info_q16(layout, mlp_depth(mlp), d) : (mlpn ? info_mlpn(mlp_depth(mlp)) : (t16 ? info_t16() : info_of(layout)));
     FusedParams p = zero_params();
     fill_encode(p, d, fi, g0, g1, origins, noise, q16 || (!mlpn && !t16));
     fill_mlp(p, mlp);
@@ -357,7 +402,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (q16) {
         rc = launch_q16_any(layout, p.n_linear, mode, p, grid, s);
         if (rc) return rc;
-        return reduce_q16_any(layout, p.n_linear, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
+        return reduce_q16_any(layout, p.n_linear, d, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
     }
     if (mlpn) {
         rc = launch_mlpn(layout, p.n_linear, mode, p, grid, s);
@@ -388,6 +433,9 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
     if (mlpn_record_floats(5) > rec) rec = mlpn_record_floats(5);
     for (int l = 1; l <= 4; ++l)
         if (q16_rec(l, 5) > rec) rec = q16_rec(l, 5);
+#define X(L, C, P) if (q16_record_floats_cp<L, C, P>() > rec) rec = q16_record_floats_cp<L, C, P>();
+    NIC_CP_LIST(X)
+#undef X
     const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float) + (1u << 20);   // one record per workgroup, at most one workgroup per CU (+ 1 MiB: diagnostic builds)
     const size_t psnr = 1024 * sizeof(double);
     return fused > psnr ? fused : psnr;
@@ -401,6 +449,20 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
+    if (d->flags & NIC_FLAG_BF16) {
+        // plain-bf16 products: the forward pass of fused_q16_kernel (every layout and channel count those kernels serve, 16-bit grids included)
+        if ((d->flags & NIC_FLAG_GRID_BF16) && (d->flags & NIC_FLAG_GRID_FP16)) return NIC_E_ARG;
+        if (!cp_default(d) && mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;
+        FusedParams p = zero_params();
+        fill_encode(p, d, info_q16(layout, mlp_depth(mlp), d), g0, g1, origins, noise, true);
+        fill_mlp(p, mlp);
+        p.y = y;
+        p.grid_kind = grid_kind_of(d);
+        balance_units(p, 1, 8);
+        if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
+        p.seg_split = 0;                                              // one segment: every macro-tile in 2^rg_log2 groups
+        return launch_q16_any(layout, p.n_linear, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 1, 8, d->max_workgroups), (hipStream_t)stream);
+    }
     bool mlpn = false;
     rc = use_mlpn(layout, d, mlp, false, mlpn, true);
     if (rc) return rc;

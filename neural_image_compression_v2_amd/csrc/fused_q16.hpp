@@ -36,76 +36,96 @@ namespace nic {
 // =====================================================================================================
 // quarter layouts
 // =====================================================================================================
-template <int METHOD>
+// C = FEATURE_PYRAMID_CHANNELS (var2.py:68; a multiple of 4: a quarter blends C / 4 G1 channels), P = PE_CHANNELS (var2.py:69; even).  The
+// reference's defaults are 12 and 6; the other widths exist for the plain-bf16 kernels only.
+template <int METHOD, int C = 12, int P = 6>
 struct QL;
 
+__host__ __device__ constexpr int align4(int v) { return (v + 3) & ~3; }
+
+// 2D (Cin = 5 C + 2 P + 1): G0 corner g [C] | G1 channels GQ g .. [GQ = C / 4] | zero padding to a multiple of 4 | PE rows (P / 2) g .. of
+// dimension g >> 1 [P / 2] | LOD (g = 0) / the constant one (g = 1) | zero padding.  C = 12, P = 6: the 20 slots of fused_train16.hpp.
+template <int C_, int P_, int PE_>
 struct QL2D {
-    static constexpr int DIM = 2, CIN = 73, K0 = 4, K1 = 4, NG0 = 1, NS = 20;
+    static constexpr int DIM = 2, C = C_, P = P_, PE = PE_, GQ = C / 4, PH = P / 2;
+    static constexpr int CIN = 5 * C + 2 * P + 1, K0 = 4, K1 = 4, NG0 = 1;
     static constexpr bool TETRA = false;
-    static constexpr int LD1 = 80, LDX = 88;
-    __host__ __device__ static constexpr int slot_channel(int s, int g) { return slot16_channel(s, g); }
-    // in-kernel noise (oracle/nic_oracle.py::_kernel_noise_2d): quarter g consumes generator block g; field of slot s (-1: none)
-    static constexpr int NBLK = 1;
-    __host__ __device__ static constexpr int noise_blk(int) { return 0; }
-    __host__ __device__ static constexpr int noise_fld(int s) { return s < 15 ? s : (s == 15 ? -1 : s - 1); }
+    static constexpr int NGS = C + GQ, T0 = align4(NGS), NS = align4(T0 + PH + 1);
+    static_assert(C % 4 == 0 && P % 2 == 0 && C >= 4 && P >= 2, "channel counts");
+    __host__ __device__ static constexpr int slot_channel(int s, int g) {
+        if (s < C) return C * g + s;
+        if (s < NGS) return 4 * C + GQ * g + (s - C);
+        if (s < T0) return kSlotZero;
+        if (s < T0 + PH) return 5 * C + PH * g + (s - T0);
+        if (s == T0 + PH) return g == 0 ? CIN - 1 : (g == 1 ? kSlotOne : kSlotZero);
+        return kSlotZero;
+    }
 };
-template <>
-struct QL<1> : QL2D {
-    static constexpr int PE = NIC_PE_TRIANGULAR;
-};
-template <>
-struct QL<2> : QL2D {
-    static constexpr int PE = NIC_PE_SINUSOIDAL;
-};
+template <int C, int P>
+struct QL<1, C, P> : QL2D<C, P, NIC_PE_TRIANGULAR> {};
+template <int C, int P>
+struct QL<2, C, P> : QL2D<C, P, NIC_PE_SINUSOIDAL> {};
 // 3D: the 20 tail values (18 PE rows, LOD, the constant one) are dealt out five per quarter: PE rows 4g .. 4g+3, then row 16 / row 17 / LOD / one
 __host__ __device__ constexpr int tail3d_channel(int j, int g, int pe0) {      // pe0: first PE channel; LOD = pe0 + 18
     if (j < 4) return pe0 + 4 * g + j;
     return g == 0 ? pe0 + 16 : (g == 1 ? pe0 + 17 : (g == 2 ? pe0 + 18 : kSlotOne));
 }
-template <>
-struct QL<4> {                                                                  // tetrahedral G0 (fp_def.py:107-112, 187-223): Cin = 79
-    static constexpr int DIM = 3, CIN = 79, K0 = 4, K1 = 8, NG0 = 1, NS = 20;
+// tetrahedral G0 (fp_def.py:107-112, 187-223): Cin = 5 C + 19: corner g [C] | G1 [GQ] | tail [5] | zero padding
+template <int C_, int P_>
+struct QL<4, C_, P_> {
+    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4;
+    static constexpr int CIN = 5 * C + 19, K0 = 4, K1 = 8, NG0 = 1;
     static constexpr bool TETRA = true;
     static constexpr int PE = NIC_PE_SINUSOIDAL;                                // fp_def.py:208
-    static constexpr int LD1 = 80, LDX = 88;
+    static constexpr int NGS = C + GQ, T0 = NGS, NS = align4(NGS + 5);
+    static_assert(C % 4 == 0 && P == 6, "3D: PE_CHANNELS 6");
     __host__ __device__ static constexpr int slot_channel(int s, int g) {
-        if (s < 12) return 12 * g + s;
-        if (s < 15) return 48 + 3 * g + (s - 12);
-        return tail3d_channel(s - 15, g, 60);
+        if (s < C) return C * g + s;
+        if (s < NGS) return 4 * C + GQ * g + (s - C);
+        if (s < NGS + 5) return tail3d_channel(s - NGS, g, 5 * C);
+        return kSlotZero;
     }
-    // in-kernel noise: quarter g consumes block g, field = slot (the constant one of quarter 3 takes none)
-    static constexpr int NBLK = 1;
-    __host__ __device__ static constexpr int noise_blk(int) { return 0; }
-    __host__ __device__ static constexpr int noise_fld(int s) { return s; }
 };
-template <>
-struct QL<3> {                                                                  // 8 raw G0 corners (fp_def.py:89-104, 148-184): Cin = 127
-    static constexpr int DIM = 3, CIN = 127, K0 = 8, K1 = 8, NG0 = 2, NS = 32;
+// 8 raw G0 corners (fp_def.py:89-104, 148-184): Cin = 9 C + 19: corners 2g, 2g + 1 [2 C] (dx = g >> 1, dy = g & 1, dz = s / C) | G1 [GQ] | tail [5] | zero padding
+template <int C_, int P_>
+struct QL<3, C_, P_> {
+    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4;
+    static constexpr int CIN = 9 * C + 19, K0 = 8, K1 = 8, NG0 = 2;
     static constexpr bool TETRA = false;
     static constexpr int PE = NIC_PE_TRIANGULAR;                                // fp_def.py:169
-    static constexpr int LD1 = 144, LDX = 136;                                  // 288-byte weight rows: b128 row reads spread over the banks (ab/w16/banks.py model)
+    static constexpr int NGS = 2 * C + GQ, T0 = NGS, NS = align4(NGS + 5);
+    static_assert(C % 4 == 0 && P == 6, "3D: PE_CHANNELS 6");
     __host__ __device__ static constexpr int slot_channel(int s, int g) {
-        if (s < 24) return 24 * g + s;                                          // corner 2g + s / 12: dx = g >> 1, dy = g & 1, dz = s / 12
-        if (s < 27) return 96 + 3 * g + (s - 24);
-        return tail3d_channel(s - 27, g, 108);
+        if (s < 2 * C) return 2 * C * g + s;
+        if (s < NGS) return 8 * C + GQ * g + (s - 2 * C);
+        if (s < NGS + 5) return tail3d_channel(s - NGS, g, 9 * C);
+        return kSlotZero;
     }
-    // in-kernel noise: quarter g consumes blocks 2g (corner 2g, G1, tail: fields 0 .. 19) and 2g + 1 (corner 2g + 1: fields 0 .. 11)
-    static constexpr int NBLK = 2;
-    __host__ __device__ static constexpr int noise_blk(int s) { return (s >= 12 && s < 24) ? 1 : 0; }
-    __host__ __device__ static constexpr int noise_fld(int s) { return s < 12 ? s : (s < 24 ? s - 12 : s - 12); }
 };
 
 template <class Q>
 struct QInfo {
-    static constexpr int NG0V = 12 * Q::NG0;                   // raw G0 values / G0 gradient sums per lane
-    static constexpr int NG1V = 3 * Q::K1;                     // raw G1 values / G1 gradient sums per lane
-    static constexpr int NGS = NG0V + 3;                       // grid slots of a quarter (they come first)
+    static constexpr int NG0V = Q::C * Q::NG0;                 // raw G0 values / G0 gradient sums per lane
+    static constexpr int NG1V = Q::GQ * Q::K1;                 // raw G1 values / G1 gradient sums per lane
+    static constexpr int NGS = Q::NGS;                         // grid slots of a quarter (they come first)
     static constexpr int KF = Q::NS / 8;                       // full k-steps of layer 1 (32 columns each)
     static constexpr bool HALF = (Q::NS % 8) != 0;             // + a compact half k-step (4 slots per quarter, 16 columns)
     static constexpr int KP = 4 * Q::NS;                       // columns of the X / W1 images
     static constexpr int NDX = (NGS + 3) / 4;                  // dX tiles (4 slots each) that hold grid slots
-    static constexpr int NT1 = 2 * KF;                         // 32x32 tiles of dW1's full k-steps
-    static_assert(Q::NS % 4 == 0 && (NT1 == 4 || NT1 == 8), "layout");
+    static constexpr int NT1 = 2 * KF;                         // 32x32 tiles of dW1's full k-steps: tile to * KF + tk (row half to, column block tk)
+    static constexpr int LD1 = KP <= 80 ? 80 : 144;            // W1 image row stride: 160- / 288-byte rows spread b128 row reads over the banks (ab/w16/banks.py)
+    static constexpr int LDX = KP + 8;
+    static_assert(Q::NS % 4 == 0 && NT1 >= 2 && NT1 <= 8 && KP <= 128, "layout");
+    // in-kernel noise (oracle/nic_oracle.py::kernel_noise_quarter): the real slots of a quarter, in slot order, take six-bit fields 0, 1, 2, ..;
+    // 20 fields per generator block, quarter g consumes blocks NBLK g ..
+    __host__ __device__ static constexpr int noise_index(int s) { return s < NGS ? s : (s >= Q::T0 && Q::slot_channel(s, 0) != kSlotZero ? NGS + (s - Q::T0) : -1); }
+    __host__ __device__ static constexpr int n_real() {
+        int n = 0;
+        for (int s = 0; s < Q::NS; ++s)
+            if (noise_index(s) >= 0) n = noise_index(s) + 1;
+        return n;
+    }
+    static constexpr int NBLK = (n_real() + 19) / 20;
     // compact input column of (slot, quarter) and its inverse
     __host__ __device__ static constexpr int rho(int s, int g) { return s < 8 * KF ? 32 * (s >> 3) + 8 * g + (s & 7) : 32 * KF + 4 * g + (s - 8 * KF); }
     __host__ __device__ static constexpr int channel_of_rho(int r) {
@@ -123,7 +143,7 @@ template <class Q, int NL>
 struct LdsQ {
     using I = QInfo<Q>;
     static constexpr int NH = NL - 2;                          // hidden 64 x 64 layers
-    static constexpr int LD1 = Q::LD1, LDH = 80, LDZ = 72, LDX = Q::LDX;
+    static constexpr int LD1 = I::LD1, LDH = 80, LDZ = 72, LDX = I::LDX;
     static constexpr int OFF_W1 = 0;                           // [64][LD1]
     static constexpr int OFF_WH = OFF_W1 + kH * LD1;           // NH x [64][LDH], columns in position order
     static constexpr int WSZ = kH * LDH;
@@ -140,8 +160,8 @@ struct LdsQ {
     static constexpr int SPW = OFF_D3 + 64;
     static constexpr int TOTAL = OFF_IMG + 8 * SPW;
     // phases of the backward pass: j = 0 .. NH - 1 = hidden layer NH - 1 - j, j = NH = layer 1.  Phase j belongs to half j & 1, accumulator slot j >> 1;
-    // with 8 dW1 tiles (method 3) every wave owns one of them: the half that does not own phase NH keeps it in an extra slot
-    static constexpr int NACC = (NH + 2) / 2 + (I::NT1 == 8 ? 1 : 0), XSLOT = (NH + 2) / 2;
+    // with more than 4 dW1 tiles (6 or 8: wide input layouts) wave w owns tile w: the half that does not own phase NH keeps it in an extra slot
+    static constexpr int NACC = (NH + 2) / 2 + (I::NT1 > 4 ? 1 : 0), XSLOT = (NH + 2) / 2;
     static constexpr int TAIL_HALF = (NH + 1) & 1;                                   // HALF: the 16-column tail of dW1 goes to the half that idles in phase NH
     __host__ __device__ static constexpr int dz_buf(int store) { return DZB == 2 ? (store & 1) : 0; }   // store 0: a_NH (forward), store 1 + j: the dZ of phase j
     static_assert(TOTAL * 2 <= 163840, "LDS");
@@ -229,7 +249,7 @@ __device__ __forceinline__ void gather_cell_q(const FusedParams& p, uint32_t off
     for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
         int dx, dy, dz;
         q_g1_corner<Q>(q, dx, dy, dz);
-        o1[q] = off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(3 * g) * (uint32_t)p.g1.plane;
+        o1[q] = off1 + (uint32_t)p.g1.at(dx, dy, dz) + (uint32_t)(Q::GQ * g) * (uint32_t)p.g1.plane;
     }
     const char* b0 = reinterpret_cast<const char*>(p.g0.p);
     const char* b1 = reinterpret_cast<const char*>(p.g1.p);
@@ -239,13 +259,13 @@ __device__ __forceinline__ void gather_cell_q(const FusedParams& p, uint32_t off
         for (int e = 0; e < (DO_G0 ? Q::NG0 : 0); ++e) {
             uint32_t ob = o0[e] * 4u;
 #pragma unroll
-            for (int c = 0; c < kC; ++c, ob += pb0) raw.g0[e * kC + c] = *reinterpret_cast<const float*>(b0 + ob);
+            for (int c = 0; c < Q::C; ++c, ob += pb0) raw.g0[e * Q::C + c] = *reinterpret_cast<const float*>(b0 + ob);
         }
 #pragma unroll
         for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
             uint32_t ob = o1[q] * 4u;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc, ob += pb1) raw.g1[q * 3 + cc] = *reinterpret_cast<const float*>(b1 + ob);
+            for (int cc = 0; cc < Q::GQ; ++cc, ob += pb1) raw.g1[q * Q::GQ + cc] = *reinterpret_cast<const float*>(b1 + ob);
         }
     } else {
         const uint32_t pb0 = (uint32_t)p.g0.plane * 2u, pb1 = (uint32_t)p.g1.plane * 2u;
@@ -254,13 +274,13 @@ __device__ __forceinline__ void gather_cell_q(const FusedParams& p, uint32_t off
         for (int e = 0; e < (DO_G0 ? Q::NG0 : 0); ++e) {
             uint32_t ob = o0[e] * 2u;
 #pragma unroll
-            for (int c = 0; c < kC; ++c, ob += pb0) h0[e * kC + c] = *reinterpret_cast<const uint16_t*>(b0 + ob);
+            for (int c = 0; c < Q::C; ++c, ob += pb0) h0[e * Q::C + c] = *reinterpret_cast<const uint16_t*>(b0 + ob);
         }
 #pragma unroll
         for (int q = 0; q < (DO_G1 ? Q::K1 : 0); ++q) {
             uint32_t ob = o1[q] * 2u;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc, ob += pb1) h1[q * 3 + cc] = *reinterpret_cast<const uint16_t*>(b1 + ob);
+            for (int cc = 0; cc < Q::GQ; ++cc, ob += pb1) h1[q * Q::GQ + cc] = *reinterpret_cast<const uint16_t*>(b1 + ob);
         }
         const bool is_bf = kind == 1;
 #pragma unroll
@@ -284,28 +304,34 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
     kf[0] = ax.k1; kf[1] = ay.k1; kf[2] = az.k1;
 #pragma unroll
     for (int c = 0; c < I::NG0V; ++c) xs[c] = raw.g0[c];
-    // ---- tail: PE rows, LOD, the constant one
+    // ---- tail: PE rows, LOD, the constant one, zero padding
     if constexpr (D == 2) {
-        xs[15] = 0.f;
-        const float c = (g >> 1) ? ay.t1 : ax.t1;                       // rows 3 (g & 1) + i of dimension g >> 1 (utils.py:198-227)
+        constexpr int T0 = Q::T0, PH = Q::PH;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = 3 * (g & 1) + i;
+        for (int s = I::NGS; s < T0; ++s) xs[s] = 0.f;
+        const float c = (g >> 1) ? ay.t1 : ax.t1;                       // rows PH (g & 1) + i of dimension g >> 1 (utils.py:198-227)
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const int r = PH * (g & 1) + i;
             float v;
             if (Q::PE == NIC_PE_TRIANGULAR) {
-                v = tri_pe_row(c, r, kP);
+                v = tri_pe_row(c, r, Q::P);
             } else {
                 const int k = r >> 1;
-                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
+                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : (k == 2 ? d.pe_div[2] : d.pe_div[3]));
                 float sv, cv;
                 sincos_cw(mul_rn(c, dv), sv, cv);
                 v = (r & 1) ? cv : sv;
             }
-            xs[16 + i] = v;
+            xs[T0 + i] = v;
         }
-        xs[19] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
+        xs[T0 + PH] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
+#pragma unroll
+        for (int s = T0 + PH + 1; s < Q::NS; ++s) xs[s] = 0.f;
     } else {
-        constexpr int T0 = I::NGS;                                      // first tail slot
+        constexpr int T0 = Q::T0;                                       // first tail slot
+#pragma unroll
+        for (int s = T0 + 5; s < Q::NS; ++s) xs[s] = 0.f;
         if constexpr (Q::PE == NIC_PE_TRIANGULAR) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -316,11 +342,11 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
                 xs[T0 + j] = j < 4 ? v : (g < 2 ? v : (g == 2 ? d.lod_value : 1.0f));
             }
         } else {
-            // rows 2 P, 2 P + 1 = (sin, cos) of pair P: dimension P / 3, frequency P % 3.  Quarter g: pairs 2g, 2g + 1, and pair 8 (rows 16, 17)
+            // rows 2 U, 2 U + 1 = (sin, cos) of pair U: dimension U / 3, frequency U % 3.  Quarter g: pairs 2g, 2g + 1, and pair 8 (rows 16, 17)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int P = u < 2 ? 2 * g + u : 8;
-                const int dm = P >= 6 ? 2 : (P >= 3 ? 1 : 0), k = P - 3 * dm;
+                const int U = u < 2 ? 2 * g + u : 8;
+                const int dm = U >= 6 ? 2 : (U >= 3 ? 1 : 0), k = U - 3 * dm;
                 const float c = dm == 0 ? ax.t1 : (dm == 1 ? ay.t1 : az.t1);
                 const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
                 float sv, cv;
@@ -333,12 +359,12 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
     // ---- G1 blend with the reference's factor order (fp_def.py:141-144, 176-183, 215-222)
     const G1Factors gf = g1_factors<D>(d.g1_weight_mode, kf[0], kf[1], kf[2]);
 #pragma unroll
-    for (int cc = 0; cc < 3; ++cc) {
+    for (int cc = 0; cc < Q::GQ; ++cc) {
         float sum = 0.f;
 #pragma unroll
         for (int c8 = 0; c8 < Q::K1; ++c8) {
             const uint32_t b = (gf.bits >> (3 * c8)) & 7u;
-            float v = raw.g1[c8 * 3 + cc];
+            float v = raw.g1[c8 * Q::GQ + cc];
             v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
             v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
             if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
@@ -363,16 +389,17 @@ __device__ __forceinline__ void add_noise_q(const NoiseSrc& ns, uint64_t sample_
         }
         return;
     }
-    U4 b[Q::NBLK];
+    using I = QInfo<Q>;
+    U4 b[I::NBLK];
 #pragma unroll
-    for (int i = 0; i < Q::NBLK; ++i) b[i] = noise_block(ns, sample_global, Q::NBLK * g + i);
+    for (int i = 0; i < I::NBLK; ++i) b[i] = noise_block(ns, sample_global, I::NBLK * g + i);
 #pragma unroll
     for (int s = 0; s < Q::NS; ++s) {
-        const int f = Q::noise_fld(s);
+        const int f = I::noise_index(s);
         if (f < 0) continue;
         const bool r0 = Q::slot_channel(s, 0) >= 0, r1 = Q::slot_channel(s, 1) >= 0, r2 = Q::slot_channel(s, 2) >= 0, r3 = Q::slot_channel(s, 3) >= 0;
         if (!(r0 || r1 || r2 || r3)) continue;
-        const float v = noise_field(ns, b[Q::noise_blk(s)], f);
+        const float v = noise_field(ns, b[f / 20], f % 20);
         if (r0 && r1 && r2 && r3) xs[s] += v;
         else xs[s] += (g == 0 ? r0 : (g == 1 ? r1 : (g == 2 ? r2 : r3))) ? v : 0.f;
     }
@@ -475,7 +502,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     constexpr int NH = S::NH, D = Q::DIM, NS = Q::NS, KF = I::KF, NDX = I::NDX, NG0T = I::NG0V / 4;
     constexpr bool HALF = I::HALF;
     constexpr int LD1 = S::LD1, LDH = S::LDH, LDZ = S::LDZ, LDX = S::LDX;
-    static_assert(MODE != MODE_INFER && (NL == 3 || NL == 5), "training kernel, 3 or 5 Linear layers");
+    static_assert(NL == 3 || NL == 5, "3 or 5 Linear layers");
+    constexpr bool TRAIN = MODE != MODE_INFER;                  // MODE_INFER: the forward pass alone (decode_image for the layouts only these kernels serve)
     // raw grid values gathered once per macro-tile (every sample a lane handles there lies in the same G0 / G1 cell) and kept in registers where
     // the budget of two waves per SIMD allows, otherwise re-fetched at the end of every round for the next one (L1 / L2 hits; dead through
     // the forward and backward passes): NIC_Q16_HOIST bit 0: G0 kept, bit 1: G1 kept
@@ -484,10 +512,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #else
     // measured (4K / 128^3 launches, interleaved A/B on one box, hoist 0 / 1 / 3): 2D NL 3: 1.51 / 1.49 / 1.45 ms, NL 5: 3.65 / 3.77 / 4.25 (spills);
     // method 4: 0.616 / 0.558 / 0.543 ms; method 3: 0.525 / 0.539 / 0.601 (spills)
-    constexpr int HOIST = NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : 0;
+    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : 0);
 #endif
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
-    __shared__ __attribute__((aligned(16))) __bf16 smemq[S::TOTAL];
+    __shared__ __attribute__((aligned(16))) __bf16 smemq[TRAIN ? S::TOTAL : S::OFF_IMG];
     lds_bf* const sm = (lds_bf*)smemq;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -522,7 +550,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);
     for (int idx = tid; idx < (NH + 1) * kH; idx += 512) Bs[idx] = p.b[idx / kH][idx % kH];
     if (tid < 4) Bs[(NH + 1) * kH + tid] = tid < 3 ? p.b[NL - 1][tid] : 0.f;
-    for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
+    if (TRAIN)
+        for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
     __syncthreads();
 
     // ---------------- launch-lifetime accumulators: the weight-gradient tiles this wave owns
@@ -563,7 +592,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     const int tiles_per_crop = (int)p.tiles_per_crop, tiles_main = (int)p.tiles_main;
     const int rounds_unit = (p.niter * p.passes) >> rg;
     const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);
-    const int shift = (NIC_STAGGER && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+    const int shift = (TRAIN && NIC_STAGGER && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
     const bool packed = p.pk_nc > 0;                                    // launch-uniform
     const int pk[3] = {p.pk_bx, p.pk_by, packed ? p.pk_nc / (p.pk_bx * p.pk_by) : 1};
 
@@ -657,7 +686,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 }
                 // ---------- target (or incoming dY) of the sample: fetched now, used after the forward pass
                 float tgt[3] = {0.f, 0.f, 0.f};
-                if (MODE == MODE_TRAIN_IMG) {
+                if (!TRAIN) {
+                } else if (MODE == MODE_TRAIN_IMG) {
                     int64_t off = (int64_t)q[0] * p.timg_s[0] + (int64_t)q[1] * p.timg_s[1];
                     if (D == 3) off += (int64_t)q[2] * p.timg_s[2];
                     uint32_t rgbx = 0u;
@@ -696,7 +726,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int s = 0; s < KF; ++s) {
                         const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6], xs[8 * s + 7]};
                         const bf16x8 bf = cvt8(xv);
-                        st_frag(&x_st[32 * s], bf);
+                        if (TRAIN) st_frag(&x_st[32 * s], bf);
                         kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
                     }
                     if constexpr (HALF) {   // slots 8 KF .. 8 KF + 3: compact columns 32 KF + 4 g + j
@@ -705,7 +735,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         const float xv[8] = {xs[8 * KF], xs[8 * KF + 1], xs[8 * KF + 2], xs[8 * KF + 3], 0.f, 0.f, 0.f, 0.f};
                         const bf16x8 bf = cvt8(xv);
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf);
-                        *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
+                        if (TRAIN) *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
                         kstep_b<4>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
                     }
                 }
@@ -728,7 +758,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[(k + 1) * kH + 16 * t]);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        st_frag(&a_st[32 * s], af[s]);
+                        if (TRAIN) st_frag(&a_st[32 * s], af[s]);
                         kstep_b<4>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
                     }
 #pragma unroll
@@ -750,7 +780,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     f32x4 z3;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        st_frag(&dz_st[32 * s], af[s]);
+                        if (TRAIN) st_frag(&dz_st[32 * s], af[s]);
                         z3 = mfma16_bf(ld_frag(&wo_row[32 * s]), af[s], s == 0 ? f32x4(0.f) : z3);
                     }
 #pragma unroll
@@ -760,6 +790,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 if (p.y != nullptr && own) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) p.y[n * 3 + c] = yv[c];
+                }
+                if (!TRAIN) {
+                    if (p.y_u8 != nullptr && own) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) p.y_u8[n * 3 + c] = (uint8_t)(int)floorf(add_rn(mul_rn(yv[c], 255.0f), 0.5f));      // quantize_to_bit (models.py:39-40)
+                    }
+                    continue;
                 }
                 // ---------- dZ_out
 #pragma unroll
@@ -884,13 +921,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         return join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
                     });
                 }
-                // G1 slots: I::NG0V .. + 2 = registers 0 .. 2 of tile NG0T
+                // G1 slots I::NG0V .. + GQ - 1: registers of tile NG0T (and the next one when GQ = 4 .. never: NG0V is a multiple of 4, GQ <= 4)
                 const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, kf[0], kf[1], kf[2]);
 #pragma unroll
                 for (int c8 = 0; c8 < Q::K1; ++c8) {
                     const float w = g1_corner_factor<D>(gf, c8);
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) g1s[c8 * 3 + cc] = fmaf(dxacc[NG0T][cc], w, g1s[c8 * 3 + cc]);
+                    for (int cc = 0; cc < Q::GQ; ++cc) g1s[c8 * Q::GQ + cc] = fmaf(dxacc[(I::NG0V + cc) >> 2][(I::NG0V + cc) & 3], w, g1s[c8 * Q::GQ + cc]);
                 }
             }
             // not hoisted: the next round's raw values are fetched HERE - in flight across the dW1 phase and the round-end barrier, where
@@ -904,11 +941,12 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             barrier();
             {
                 const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
-                if constexpr (I::NT1 == 4) {
-                    if (kh == (NH & 1)) {
-                        // dW1, the 64 columns of the full k-steps: tile (to, tk) over all eight source waves
-                        lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
-                        lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
+                if constexpr (I::NT1 <= 4) {
+                    if (kh == (NH & 1) && T4 < I::NT1) {
+                        // dW1, the columns of the full k-steps: tile T4 = (row half T4 / KF, column block T4 % KF) over all eight source waves
+                        const int t1o = T4 / KF, t1k = T4 - t1o * KF;
+                        lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * t1o + 16 * cg + 4 * p4));
+                        lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * t1k + 16 * cg + 4 * p4));
 #pragma unroll
                         for (int v = 0; v < 8; ++v) {
                             const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
@@ -916,10 +954,11 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                             accW[NH >> 1] = mfma_bf(a, b, accW[NH >> 1]);
                         }
                     }
-                } else {
-                    // 128 columns: every wave owns one of the 8 tiles - (row half wave >> 2, column block wave & 3) - over all eight source waves
-                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * kh + 16 * cg + 4 * p4));
-                    lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * T4 + 16 * cg + 4 * p4));
+                } else if (wave < I::NT1) {
+                    // 6 or 8 tiles: wave w owns tile w = (row half w / KF, column block w % KF) over all eight source waves
+                    const int t1o = wave / KF, t1k = wave - t1o * KF;
+                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * t1o + 16 * cg + 4 * p4));
+                    lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * t1k + 16 * cg + 4 * p4));
                     f32x16 c = kh == (NH & 1) ? accW[NH >> 1] : accW[S::XSLOT];
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
@@ -951,7 +990,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
-        {
+        if (TRAIN) {
             const int ln = opaque_i(lane), g = ln >> 4;
             combine_g1_lanes_q<Q>(g1s, blk_off1, blk, ln, lw, packed, pk, pk_lc);
             bool flush = true;
@@ -996,14 +1035,14 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 for (int e = 0; e < Q::NG0; ++e) {
                     uint32_t nz0 = 0u;
 #pragma unroll
-                    for (int c = 0; c < kC; ++c) nz0 |= __builtin_bit_cast(uint32_t, dxacc[(e * kC + c) >> 2][(e * kC + c) & 3]);
+                    for (int c = 0; c < Q::C; ++c) nz0 |= __builtin_bit_cast(uint32_t, dxacc[(e * Q::C + c) >> 2][(e * Q::C + c) & 3]);
                     if ((nz0 << 1) != 0u) {
                         int dx, dy, dz;
                         q_g0_corner<Q>(g, e, dx, dy, dz);
                         uint32_t ob = (blk_off0 + (uint32_t)p.g0.at(dx, dy, dz)) * 4u;
                         char* gbase = reinterpret_cast<char*>(p.g0_grad);
 #pragma unroll
-                        for (int c = 0; c < kC; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), dxacc[(e * kC + c) >> 2][(e * kC + c) & 3]);
+                        for (int c = 0; c < Q::C; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), dxacc[(e * Q::C + c) >> 2][(e * Q::C + c) & 3]);
                     }
                 }
                 uint32_t nz1 = 0u;
@@ -1014,10 +1053,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int c8 = 0; c8 < Q::K1; ++c8) {
                         int dx, dy, dz;
                         q_g1_corner<Q>(c8, dx, dy, dz);
-                        uint32_t ob = (blk_off1 + (uint32_t)p.g1.at(dx, dy, dz)) * 4u + (uint32_t)(3 * g) * pb1;
+                        uint32_t ob = (blk_off1 + (uint32_t)p.g1.at(dx, dy, dz)) * 4u + (uint32_t)(Q::GQ * g) * pb1;
                         char* gbase = reinterpret_cast<char*>(p.g1_grad);
 #pragma unroll
-                        for (int cc = 0; cc < 3; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), g1s[c8 * 3 + cc]);
+                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), g1s[c8 * Q::GQ + cc]);
                     }
                 }
             }
@@ -1033,6 +1072,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     }
 #endif
 
+    if (!TRAIN) return;
     // ---------------- one record per workgroup
     float* rec = p.partials + (int64_t)blockIdx.x * S::REC;
 #pragma unroll
@@ -1087,8 +1127,9 @@ __global__ void __launch_bounds__(256) reduce_q16_kernel(const float* partials, 
             if (r < 32 * KF) {
                 // phase NH: the tile's owner wave and accumulator slot (LdsQ)
                 int w, slot;
-                if (I::NT1 == 4) { w = 4 * (NH & 1) + 2 * (po >> 5) + (r >> 5); slot = NH >> 1; }
-                else { w = 4 * (po >> 5) + (r >> 5); slot = (w >> 2) == (NH & 1) ? NH >> 1 : S::XSLOT; }
+                const int tile = (po >> 5) * KF + (r >> 5);
+                if (I::NT1 <= 4) { w = 4 * (NH & 1) + tile; slot = NH >> 1; }
+                else { w = tile; slot = (w >> 2) == (NH & 1) ? NH >> 1 : S::XSLOT; }
                 off0 = S::REC_W + (w * S::NACC + slot) * 1024 + tile32(po & 31, r & 31);
             } else {
                 const int m = po & 15;

@@ -11,6 +11,7 @@ static int launch_q16_nl(int mode, const FusedParams& p, int grid, hipStream_t s
     if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_MSE, NL>), g, b, 0, s, p);
     else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_IMG, NL>), g, b, 0, s, p);
     else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_DY, NL>), g, b, 0, s, p);
+    else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_INFER, NL>), g, b, 0, s, p);
     else return NIC_E_UNSUPPORTED;
     return (int)hipGetLastError();
 }
@@ -33,5 +34,18 @@ static int reduce_q16_nl(const float* partials, int n_rec, nic_mlp_grads g, floa
     }                                                                                                                            \
     template <>                                                                                                                  \
     int q16_record_floats<METHOD>(int n_linear) { return n_linear == 5 ? LdsQ<QL<METHOD>, 5>::REC : LdsQ<QL<METHOD>, 3>::REC; }
+
+// non-default channel counts (FEATURE_PYRAMID_CHANNELS / PE_CHANNELS, var2.py:68-69): 3-layer decoder only; one translation unit per (method, C, P)
+#define NIC_INSTANTIATE_Q16_CP(METHOD, C, P)                                                                                     \
+    template <>                                                                                                                  \
+    int launch_q16_cp<METHOD, C, P>(int mode, const FusedParams& p, int grid, hipStream_t s) {                                   \
+        return launch_q16_nl<QL<METHOD, C, P>, 3>(mode, p, grid, s);                                                             \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int reduce_q16_cp<METHOD, C, P>(const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
+        return reduce_q16_nl<QL<METHOD, C, P>, 3>(partials, n_rec, g, loss, loss_scale, s);                                      \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int q16_record_floats_cp<METHOD, C, P>() { return LdsQ<QL<METHOD, C, P>, 3>::REC; }
 
 }  // namespace nic

@@ -17,4 +17,11 @@ template <int METHOD>
 int reduce_q16(int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
 template <int METHOD>
 int q16_record_floats(int n_linear);
+// .. with non-default channel counts C = FEATURE_PYRAMID_CHANNELS, P = PE_CHANNELS (3 Linear layers; fused_qc_*.hip)
+template <int METHOD, int C, int P>
+int launch_q16_cp(int mode, const FusedParams& p, int grid, hipStream_t s);
+template <int METHOD, int C, int P>
+int reduce_q16_cp(const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+template <int METHOD, int C, int P>
+int q16_record_floats_cp();
 }  // namespace nic

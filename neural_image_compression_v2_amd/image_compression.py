@@ -67,6 +67,9 @@ class ImageCompression:
         if c.MLP_NUM_DTYPE not in (16, 32):
             raise NotImplementedError("MLP_NUM_DTYPE is 32, or 16 = float16 grid storage (utils.py:301-313 maps 16 to torch.float16; the reference "
                                       "never casts its decoder, image_compression.py:350, and its own 16-bit run does not train, readme.md:9)")
+        if (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) != (12, 6) and not c.TF_PLAIN_BF16:
+            raise NotImplementedError("FEATURE_PYRAMID_CHANNELS / PE_CHANNELS other than 12 / 6 run on the plain-bf16 kernels: set TF_PLAIN_BF16=True "
+                                      "(C in 4, 8, 12, 16 with P = 6; P in 4, 6, 8 with C = 12 in 2D; HIDDEN_LAYER_CHANNELS 64)")
         grid_dtype = torch.bfloat16 if c.TF_GRID_BF16 else (torch.float16 if c.MLP_NUM_DTYPE == 16 else torch.float32)
         if grid_dtype != torch.float32 and c.FP_DIMENSION == 3 and not c.TF_PLAIN_BF16:
             raise NotImplementedError("16-bit grid storage in 3D runs on the plain-bf16 kernels: set TF_PLAIN_BF16=True")
@@ -348,14 +351,16 @@ class ImageCompression:
             run = (lambda geo, org: fused.fused_forward_u8(geo, ga, gb, org, params)) if stored else \
                   (lambda geo, org: fused.fused_forward(geo, ga, gb, org, params))
             split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)
+            # channel counts other than the reference's defaults exist on the plain-bf16 kernels only: their forward pass decodes
+            wide = (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) != (12, 6)
             if div_slice == 1:
-                y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split), [[0] * D])
+                y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split, bf16=wide), [[0] * D])
                 return y.reshape(*([decode_size] * D), 3)
             if D != 2:
                 raise NotImplementedError("tiled decode is 2D only, like the reference (image_compression.py:329-345)")
             s = decode_size // div_slice
             result = torch.zeros(decode_size, decode_size, 3, dtype=torch.float32, device=self.device)
-            geo = self._geometry(fl, mip_level, s, 1, split_bf16=split)
+            geo = self._geometry(fl, mip_level, s, 1, split_bf16=split, bf16=wide)
             for i in range(div_slice * div_slice):
                 tx, ty = i % div_slice, i // div_slice
                 result[s * tx:s * (tx + 1), s * ty:s * (ty + 1), :] = run(geo, [[s * tx, s * ty]]).reshape(s, s, 3)

@@ -451,3 +451,69 @@ def test_stored_codec_decode_with_the_deep_decoder(dev):
         ref = O.mlp_forward(O.create_decoder_input(deq[0], deq[1], [(0, 0)], (128, 128), 0.25, 0, 6), mlp)
         assert relmax(y8, ref) <= 5e-6
         assert torch.equal(q8.cpu(), O.quantize_to_bit(y8.cpu(), 8).to(torch.uint8))
+
+
+WIDTH_CASES = [
+    # dim, method, tri, C, P
+    (2, 1, True, 4, 6), (2, 1, False, 8, 6), (2, 1, True, 16, 6), (2, 1, False, 12, 4), (2, 1, True, 12, 8), (2, 1, False, 12, 8),
+    (3, 3, True, 4, 6), (3, 3, True, 8, 6), (3, 4, False, 4, 6), (3, 4, False, 8, 6), (3, 4, False, 16, 6),
+]
+
+
+@pytest.mark.parametrize("case", WIDTH_CASES, ids=lambda c: f"d{c[0]}m{c[1]}{'t' if c[2] else 's'}-C{c[3]}-P{c[4]}")
+def test_channel_count_flags_on_the_plain_bf16_kernels(dev, case):
+    """FEATURE_PYRAMID_CHANNELS / PE_CHANNELS other than the defaults (reference flags, var2.py:68-69): the quarter layouts
+    are templates over C and P - step (tensor and in-kernel noise, unaligned multi-crop shapes) against the emulating oracle, and the
+    forward pass (decode) of the same kernels against the emulating forward."""
+    from neural_image_compression_v2_amd import _lib, fused
+    dim, method, tri, C, P = case
+    extent = (37, 21) if dim == 2 else (9, 6, 7)
+    origins = [(3, 5), (100, 60)] if dim == 2 else [(3, 5, 9), (20, 0, 31)]
+    fp, _ = _pyramid(dim, 64 if dim == 2 else 16, C, seed=11, no_mip=True)
+    g0, g1 = fp[0], fp[1]
+    cin = O.decoder_input_channels(C, P, dim, method)
+    g = torch.Generator().manual_seed(100 + C + P)
+    mlp = O.init_mlp(cin, 64, generator=g)
+    n = len(origins) * int(np.prod(extent))
+    target = torch.rand(n, 3, generator=g)
+    params = [q.to(dev) for q in mlp.tensors()]
+    for noise_kind in ("kernel", "tensor"):
+        if noise_kind == "kernel":
+            noise = O.kernel_noise(n, cin, 8, seed=77, offset=5, sample_base=123, quarter=True, layout=(dim, method, C, P))
+            kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=77, noise_offset=5, sample_base=123)
+        else:
+            noise = (torch.rand(n, cin, generator=g) - 0.5) / 256
+            kw = dict(noise_mode=_lib.NIC_NOISE_TENSOR)
+        ref = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, P, method=method, use_tri_pe=tri, emulate="bf16")
+        ref32 = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, P, method=method, use_tri_pe=tri)
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), use_tri_pe=tri,
+                                 channels=C, pe_channels=P, bf16=True, **kw)
+        nd = noise.to(dev) if noise_kind == "tensor" else None
+        out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), nd, want_y=True)
+        check_step(out, ref, ref32, 3, f"C{C} P{P} d{dim}m{method} {noise_kind}")
+        y = fused.fused_forward(geo, g0.to(dev), g1.to(dev), origins, params, nd)
+        assert torch.equal(y, out.y), "the forward pass of the plain-bf16 kernels == the y of their training step"
+    # the split / fp32 kernels refuse these widths loudly
+    with pytest.raises(RuntimeError):
+        fused.fused_forward_backward(fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins),
+                                                        use_tri_pe=tri, channels=C, pe_channels=P, split_bf16=True),
+                                     g0.to(dev), g1.to(dev), origins, params, target.to(dev))
+
+
+def test_plain_bf16_inference_default_widths_and_16_bit_grids(dev):
+    """nic_fused_forward with NIC_FLAG_BF16: the forward pass of fused_q16_kernel for the default widths, 5 layers, 16-bit grids, 3D"""
+    from neural_image_compression_v2_amd import fused
+    g = torch.Generator().manual_seed(2)
+    for dim, method, nl, gdt in ((2, 1, 5, torch.bfloat16), (2, 1, 3, torch.float32), (3, 3, 3, torch.float16), (3, 4, 5, torch.bfloat16)):
+        extent = (70, 40) if dim == 2 else (17, 9, 8)
+        origins = [(0, 0)] if dim == 2 else [(4, 8, 12)]
+        fp, _ = _pyramid(dim, 64 if dim == 2 else 16, 12, seed=13, no_mip=True)
+        g0, g1 = fp[0].to(gdt), fp[1].to(gdt)
+        cin = O.decoder_input_channels(12, 6, dim, method)
+        mlp = O.init_mlp(cin, 64, generator=g, n_linear=nl)
+        tri = method != 4
+        x = O.create_decoder_input(g0.float(), g1.float(), origins, extent, 0.25, 0, 6, method=method, use_tri_pe=tri)
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=1, use_tri_pe=tri, bf16=True)
+        y = fused.fused_forward(geo, g0.to(dev), g1.to(dev), origins, [q.to(dev) for q in mlp.tensors()])
+        assert float((y.cpu() - _emulated_y(x, mlp)).abs().max()) <= 2e-3
+        assert float((y.cpu() - O.mlp_forward(x, mlp)).abs().max()) <= 2e-2
