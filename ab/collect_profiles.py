@@ -1,7 +1,8 @@
 """gpurun_out/prof_TAG (ab/profile.sh) -> profiles/TAG_{bench.json,kernel_stats.csv,pmc.csv} + profiles/traffic.json"""
 import csv, glob, json, os, sys
 tag = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "fused_train16_kernel"     # the dominant kernel of the default bench
+kern = sys.argv[2] if len(sys.argv) > 2 else "fused_train16_kernel"     # the dominant kernel of the default bench (substring of its name)
+update_traffic = kern.startswith("fused_train16")                       # profiles/traffic.json is the headline kernel's
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -20,7 +21,8 @@ for i in range(1, 6):
         dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     names = sorted({r["Counter_Name"] for r in rows})
     sets = open(os.path.join(src, f"pmc{i}.set")).read().strip()
-    out.append(f"# pass {i}: rocprofv3 --pmc {sets} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   "
+    extra = open(os.path.join(src, "args.txt")).read().strip() if os.path.exists(os.path.join(src, "args.txt")) else ""
+    out.append(f"# pass {i}: rocprofv3 --pmc {sets} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --stat-launches 0 {extra}   "
                f"({kern} avg {sum(dur.values()) / len(dur):.3f} ms over {len(disp)} launches)")
     for n in names:
         per = {}
@@ -36,5 +38,6 @@ traffic = {"fused_kernel_bytes_per_launch": int(2 * vals["FETCH_SIZE"] * 1024 + 
            "note": f"per launch of {kern} (Layout<1>, MODE_TRAIN_MSE) on the 4K workload; separate --pmc passes (profiles/{tag}_pmc.csv); "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of coalesced fetch bytes; the kernel's 4-12 B/lane reads are "
                    "outside the calibrated pattern, so this is an upper bound), WRITE_SIZE as is (exact for float atomics)."}
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+traffic["note"] = traffic["note"].replace("fused_train16_kernel (Layout<1>, MODE_TRAIN_MSE)", kern)
+json.dump(traffic, open(os.path.join(dst, "traffic.json" if update_traffic else f"{tag}_traffic.json"), "w"), indent=1)
 print(line[:300]); print("\n".join(out[:12])); print(traffic["fused_kernel_bytes_per_launch"])

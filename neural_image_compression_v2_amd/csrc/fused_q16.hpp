@@ -512,9 +512,19 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #else
     // measured (4K / 128^3 launches, interleaved A/B on one box, hoist 0 / 1 / 3): 2D NL 3: 1.51 / 1.49 / 1.45 ms, NL 5: 3.65 / 3.77 / 4.25 (spills);
     // method 4: 0.616 / 0.558 / 0.543 ms; method 3: 0.525 / 0.539 / 0.601 (spills)
-    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : 0);
+    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : (Q::NG0 == 1 ? 3 : 0));
 #endif
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
+    // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per layer), except - 5 layers - those of the first RECOMP
+    // layers, the longest-lived ones: they are RECOMPUTED in the backward pass from the layer's input, which still sits in the wave's own
+    // LDS image as the very fragments the forward pass multiplied (same operands, same order: the same pre-activations bit for bit).
+    // 20 more MFMAs and ~300 vector instructions per round buy 16 registers: with them the 5-layer kernel spilled 70 - 150 registers
+    // and moved 9.8 GB of scratch traffic per 4K launch (profiles/r03_c_pmc.csv: FETCH_SIZE 1.8 GB, WRITE_SIZE 6.0 GB against 0.10 / 0.16 GB).
+#ifdef NIC_Q16_RECOMP
+    constexpr int RECOMP = NIC_Q16_RECOMP;
+#else
+    constexpr int RECOMP = (TRAIN && NL == 5) ? 2 : 0;
+#endif
     __shared__ __attribute__((aligned(16))) __bf16 smemq[TRAIN ? S::TOTAL : S::OFF_IMG];
     lds_bf* const sm = (lds_bf*)smemq;
 
@@ -748,7 +758,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     gelu_and_grad4(z[2 * s], a4[0], d4[0]);
                     gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
                     af[s] = cvt_pair(a4[0], a4[1]);
-                    dpk[0][s] = cvt_pair(d4[0], d4[1]);
+                    if (0 >= RECOMP) dpk[0][s] = cvt_pair(d4[0], d4[1]);
                     NIC_Q16_SB;
                 }
 #pragma unroll
@@ -767,7 +777,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         gelu_and_grad4(z[2 * s], a4[0], d4[0]);
                         gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
                         af[s] = cvt_pair(a4[0], a4[1]);
-                        dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
+                        if (k + 1 >= RECOMP) dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
                         NIC_Q16_SB;
                     }
                 }
@@ -899,8 +909,51 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 }
                 if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
                 STAMP(4 + 2 * j);
+                if (k >= RECOMP) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+                    for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+                } else {
+                    // recompute the pre-activation whose GELU produced a_k: layer 1 (k = 0: X image, W1) or hidden layer k - 1 (A_{k-1} image)
+                    const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
+                    lds_bf* const imgw = img0 + wave * S::SPW;
+                    lds_cf* const b_row = opaque(Bs + 4 * g);
+                    f32x4 z[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[k * kH + 16 * t]);
+                    if (k == 0) {
+                        lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
+                        lds_cbf* const x_ld = opaque((lds_cbf*)(imgw + n16 * LDX + 8 * g));
+#pragma unroll
+                        for (int s = 0; s < KF; ++s) {
+                            const bf16x8 bf = ld_frag(&x_ld[32 * s]);
+                            kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
+                        }
+                        if constexpr (HALF) {
+                            lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
+                            lds_cbf* const x_ld2 = opaque((lds_cbf*)(imgw + n16 * LDX + 32 * KF + 4 * g));
+                            const bf16x8 bf = half_frag(*reinterpret_cast<lds_cs16x4*>(x_ld2));
+                            kstep_b<4>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                        }
+                    } else {
+                        lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));
+                        lds_cbf* const a_ld = opaque((lds_cbf*)(imgw + S::OFF_A + (k - 1) * S::ASZ + n16 * LDZ + 8 * g));
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const bf16x8 bf = ld_frag(&a_ld[32 * s]);
+                            kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w_row[S::OFF_WH + (k - 1) * S::WSZ + 16 * t * LDH + 32 * s]); });
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f32x4 a4[2], d4[2];
+                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
+                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
+                        const bf16x8 dp = cvt_pair(d4[0], d4[1]);           // rounded to bf16 like the kept ones
+                        dzc[2 * s] = acc[2 * s] * unpack4(dp, false);
+                        dzc[2 * s + 1] = acc[2 * s + 1] * unpack4(dp, true);
+                        NIC_Q16_SB;
+                    }
+                }
             }
             // ---------- phase NH, layer 1: dX = W1^T dZ1 for the grid slots (tile t = slots 4t .. 4t+3); tiles 0 .. NG0T-1 (the G0 channels) keep
             // their running sums over the rounds in the product's C operand; the dZ1 fragments are the dZ1 image of dW1
