@@ -67,9 +67,8 @@ class ImageCompression:
         if c.MLP_NUM_DTYPE not in (16, 32):
             raise NotImplementedError("MLP_NUM_DTYPE is 32, or 16 = float16 grid storage (utils.py:301-313 maps 16 to torch.float16; the reference "
                                       "never casts its decoder, image_compression.py:350, and its own 16-bit run does not train, readme.md:9)")
-        if (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) != (12, 6) and not c.TF_PLAIN_BF16:
-            raise NotImplementedError("FEATURE_PYRAMID_CHANNELS / PE_CHANNELS other than 12 / 6 run on the plain-bf16 kernels: set TF_PLAIN_BF16=True "
-                                      "(C in 4, 8, 12, 16 with P = 6; P in 4, 6, 8 with C = 12 in 2D; HIDDEN_LAYER_CHANNELS 64)")
+        # (FEATURE_PYRAMID_CHANNELS / PE_CHANNELS other than 12 / 6: the element-wise API path takes any C; the FUSED step and decode exist for
+        #  C in 4, 8, 12, 16 / P in 4, 6, 8 on the plain-bf16 kernels - TF_PLAIN_BF16=True - and raise NIC_E_UNSUPPORTED otherwise)
         grid_dtype = torch.bfloat16 if c.TF_GRID_BF16 else (torch.float16 if c.MLP_NUM_DTYPE == 16 else torch.float32)
         if grid_dtype != torch.float32 and c.FP_DIMENSION == 3 and not c.TF_PLAIN_BF16:
             raise NotImplementedError("16-bit grid storage in 3D runs on the plain-bf16 kernels: set TF_PLAIN_BF16=True")
