@@ -8,12 +8,13 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)           # a directory may hold an earlier run's files too
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write(open(stats).read())
 out = []
 vals = {}
 for i in range(1, 6):
-    f = glob.glob(os.path.join(src, f"pmc{i}", "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, f"pmc{i}", "*", "*_counter_collection.csv"))
     rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
     disp = sorted({int(r["Dispatch_Id"]) for r in rows})
     dur = {}

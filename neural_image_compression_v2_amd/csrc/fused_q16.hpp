@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     // layers, the longest-lived ones: they are RECOMPUTED in the backward pass from the layer's input, which still sits in the wave's own
     // LDS image as the very fragments the forward pass multiplied (same operands, same order: the same pre-activations bit for bit).
     // 20 more MFMAs and ~300 vector instructions per round buy 16 registers: with them the 5-layer kernel spilled 70 - 150 registers
-    // and moved 9.8 GB of scratch traffic per 4K launch (profiles/r03_c_pmc.csv: FETCH_SIZE 1.8 GB, WRITE_SIZE 6.0 GB against 0.10 / 0.16 GB).
+    // and moved 9.8 GB of scratch traffic per 4K launch (profiles/r03_c0_pmc.csv: FETCH_SIZE 1.8 GB, WRITE_SIZE 6.0 GB against 0.10 / 0.16 GB).
 #ifdef NIC_Q16_RECOMP
     constexpr int RECOMP = NIC_Q16_RECOMP;
 #else
