@@ -935,7 +935,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
     const int64_t n_my = base0 < t_end ? (t_end - base0 + lstride - 1) / lstride : 0;
     const int rounds_unit = (SRC == SRC_ENCODE ? p.niter * p.passes : 1) >> rg;
     const int nph = rounds_unit >= NIC_PHASES ? NIC_PHASES : (rounds_unit >= 2 ? 2 : 1);      // phases (a power of two)
-    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && (NIC_STAGGER_RG || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;
+    const int shift = (NIC_STAGGER && TRAIN && SRC == SRC_ENCODE && ((NIC_STAGGER_RG && L::DIM == 2) || rg == 0)) ? (int)((blockIdx.x >> 3) & (nph - 1)) * (rounds_unit / nph) : 0;   // 3D, rounds dealt out in groups: the extra partial unit per wave costs more than the phases gain (the reference's sweep shape 380 -> 361 us, 323 -> 294 us)
     for (int64_t kk = 0; kk < n_my + (shift ? 1 : 0); ++kk) {
         const int64_t base = base0 + (kk < n_my ? kk : 0) * lstride;
         // a wave without a tile in the last round still takes part (barriers, owned dW tiles): it recomputes the range's
