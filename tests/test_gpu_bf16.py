@@ -547,3 +547,38 @@ def test_plain_bf16_3d_sweep_fit_reaches_the_split_fits_psnr(dev, method):
         res[mode] = float(ic.psnr(fp))
     print(f"\nmethod {method}: PSNR after 200 steps: split {res['split']:.4f} dB, plain bf16 {res['bf16']:.4f} dB ({res['bf16'] - res['split']:+.4f} dB)")
     assert abs(res["bf16"] - res["split"]) <= 0.01, res               # measured: method 3 0.0000 dB, method 4 -0.0005 dB
+
+
+@pytest.mark.parametrize("kind", ["t16", "mlpn5", "q16", "q16-5", "q16-m3", "k32-m4"])
+def test_restricted_workgroup_counts_match_the_unrestricted_launch(dev, kind):
+    """nic_path_desc.max_workgroups (config 5: fits on separate streams share the CUs) changes the unit schedule, the segment split, the
+    number of per-workgroup records and the reduce input - every training kernel family must give the same step with 8, 32 or cu / 8 workgroups as
+    with the whole chip (loss and decoder gradients to summation order, grid gradients to atomic order); values below 8 mean 8."""
+    from neural_image_compression_v2_amd import _lib, fused
+    dim, method = (3, 3) if kind == "q16-m3" else ((3, 4) if kind == "k32-m4" else (2, 1))
+    nl = 5 if kind in ("mlpn5", "q16-5") else 3
+    kw = dict(bf16=True) if kind.startswith("q16") else dict(split_bf16=True)
+    extent = (100, 70) if dim == 2 else (20, 18, 11)
+    origins = [(3, 5), (100, 60), (17, 150)] if dim == 2 else [(3, 5, 9), (20, 0, 31), (11, 40, 2)]
+    fp, _ = _pyramid(dim, 64 if dim == 2 else 16, 12, seed=21, no_mip=True)
+    g0, g1 = fp[0].to(dev), fp[1].to(dev)
+    g = torch.Generator().manual_seed(33)
+    mlp = O.init_mlp(O.decoder_input_channels(12, 6, dim, method), 64, generator=g, n_linear=nl)
+    params = [q.to(dev) for q in mlp.tensors()]
+    n = len(origins) * int(np.prod(extent))
+    target = torch.rand(n, 3, generator=g).to(dev)
+    cu = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def run(mw):
+        geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=len(origins), use_tri_pe=method != 4,
+                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=3, noise_offset=9, max_workgroups=mw, **kw)
+        return fused.fused_forward_backward(geo, g0, g1, origins, params, target, want_y=True)
+    full = run(0)
+    for mw in (8, 32, cu // 8, 3):
+        r = run(mw)
+        assert torch.equal(r.y, full.y)
+        assert relmax(r.loss, full.loss) <= 2e-6
+        for a, b in zip(r.grad_mlp, full.grad_mlp):
+            assert relmax(a, b) <= 2e-5, (kind, mw)
+        assert relmax(r.grad_g0, full.grad_g0) <= 1e-5 and relmax(r.grad_g1, full.grad_g1) <= 1e-5, (kind, mw)
+    assert torch.equal(run(3).loss, run(8).loss), "fewer than 8 workgroups means 8"
