@@ -372,10 +372,14 @@ def g7_g8_mlp_fwdbwd(ref_models, ref_utils, ref_fp):
 
 
 def g8b_fwdbwd_mip0(ref_models, ref_utils, ref_fp):
-    """The default training shape (2D, no-mip, C = 12, two 256 x 256 crops, tri PE and sin PE).  Inputs are
-    regenerated from the torch CPU generator by the test (seed stored, grids digested so a changed
-    RNG stream is told apart from a parity failure); outputs are pinned by digests, row samples
-    and the full set of decoder gradients."""
+    """The default training shape (2D, no-mip, C = 12, two 256 x 256 crops, tri PE and sin PE).  The grids and the decoder
+    (drawn by the reference from the torch generator) are STORED; noise and targets come from the oracle's counter-based
+    generator (integer arithmetic in numpy: the same numbers on any torch version), so the test can rebuild every input
+    without depending on the torch RNG stream; outputs are pinned by digests, row samples and the full set of decoder gradients."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import nic_oracle as O
     out = {}
     dt = torch.float32
     for tag, tri in (("tri", True), ("sin", False)):
@@ -387,8 +391,12 @@ def g8b_fwdbwd_mip0(ref_models, ref_utils, ref_fp):
         decoder = ns["ColorDecoder"]()
         coord = torch.zeros(2, 2, dtype=torch.int64)
         x = ns["create_decoder_input_2d"](fp, coord, 2, 0, 0)
-        noise = (torch.rand_like(x) - 0.5) / (2 ** 8)
-        target = torch.rand(x.shape[0], 3)
+        noise = O.kernel_noise(x.shape[0], 73, 8, seed=seed, offset=1)                   # portable: Threefry in numpy integers
+        target = (O.kernel_noise(x.shape[0], 73, 0, seed=seed, offset=2)[:, :3] + 0.5).contiguous()      # U on a 2^-6 lattice of [0, 1)
+        out[f"{tag}_g0"] = fp[0].detach().clone()
+        out[f"{tag}_g1"] = fp[1].detach().clone()
+        for k, p in decoder.state_dict().items():
+            out[f"{tag}_sd_{k}"] = p.detach().clone()
         y = decoder(x + noise)
         loss = torch.nn.MSELoss()(y, target)
         loss.backward()
