@@ -70,9 +70,9 @@ class ImageCompression:
         # (FEATURE_PYRAMID_CHANNELS / PE_CHANNELS other than 12 / 6: the element-wise API path takes any C; the FUSED step and decode exist for
         #  C in 4, 8, 12, 16 / P in 4, 6, 8 on the plain-bf16 kernels - TF_PLAIN_BF16=True - and raise NIC_E_UNSUPPORTED otherwise)
         grid_dtype = torch.bfloat16 if c.TF_GRID_BF16 else (torch.float16 if c.MLP_NUM_DTYPE == 16 else torch.float32)
-        if grid_dtype != torch.float32 and c.FP_DIMENSION == 3 and not c.TF_PLAIN_BF16:
+        if grid_dtype != torch.float32 and c.FP_DIMENSION == 3 and not c.plain_bf16:
             raise NotImplementedError("16-bit grid storage in 3D runs on the plain-bf16 kernels: set TF_PLAIN_BF16=True")
-        if grid_dtype != torch.float32 and c.FP_DIMENSION == 2 and not (c.TF_SPLIT_BF16 or c.TF_PLAIN_BF16):
+        if grid_dtype != torch.float32 and c.FP_DIMENSION == 2 and not (c.TF_SPLIT_BF16 or c.plain_bf16):
             raise NotImplementedError("16-bit grid storage needs TF_SPLIT_BF16 or TF_PLAIN_BF16")
         if seed is not None:
             torch.manual_seed(seed)
@@ -222,7 +222,7 @@ class ImageCompression:
         if fused_step and fp[2 * fl].requires_grad:
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
-                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16), bf16=bool(c.TF_PLAIN_BF16))
+                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16)
             if isinstance(target, fused.TargetImage) and not os.environ.get("NIC_NO_PLAN"):
                 # the steady state: one prepared launch plan (and one reused gradient bucket) per (level, LOD)
                 plans = self.__dict__.setdefault("_plans", {})
@@ -244,7 +244,7 @@ class ImageCompression:
             loss = out.loss if out.loss.data_ptr() != out.flat.data_ptr() else out.loss.clone()   # a slot of the reused bucket is rewritten by the next step
         elif c.DECODER_LINEAR_LAYERS != 3:
             # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
-            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16), bf16=bool(c.TF_PLAIN_BF16),
+            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE, noise_seed=noise_seed, noise_offset=epoch)
             y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
             loss = ((y - target) ** 2).mean()

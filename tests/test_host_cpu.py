@@ -534,6 +534,17 @@ def test_counter_based_sampler_host_functions_match_the_oracle(lib):
     assert lib.nic_sampler_lod_host(0, 0, 0, -1) < 0 and lib.nic_sampler_origins_host(0, 0, 1, 2, 0, arr) < 0
 
 
+def test_settings_resolve_the_product_precision():
+    """TF_PLAIN_BF16 = -1 (default): plain-bf16 products for 3D fits (the reference's sweeps; PSNR-equivalent to the split fits, tests/test_gpu_bf16.py),
+    split products in 2D; explicit values win; the argv form of the reference's flag system parses it"""
+    from neural_image_compression_v2_amd.var2 import Settings
+    assert Settings().plain_bf16 is False
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3).plain_bf16 is True and Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=4).plain_bf16 is True
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=2).plain_bf16 is False              # method 2: a 3D volume flattened to a 2D pyramid
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, TF_PLAIN_BF16=False).plain_bf16 is False and Settings(TF_PLAIN_BF16=True).plain_bf16 is True
+    assert Settings.from_argv(["TF_PLAIN_BF16=1"]).plain_bf16 is True and Settings.from_argv(["IMAGE_DIMENSION=3", "TF_PLAIN_BF16=0"]).plain_bf16 is False
+
+
 def test_light_cosine_scheduler_is_torchs_bit_for_bit():
     """optim.CosineAnnealing replaces torch's CosineAnnealingLR in the training loop (70 us of host time per step): the learning rates
     of both groups must be the same doubles over whole schedules, including steps past T_max (the restart branch)."""
