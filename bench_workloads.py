@@ -72,25 +72,21 @@ _DT = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "
 
 
 def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=True, shapes=None):
-    """one crop = the whole volume (or slab) per step"""
-    from neural_image_compression_v2_amd import _lib, fused
-    lib = _lib.load()
-    st = _fit_state(dev, dim, method, grid_base, shapes=shapes)
+    """one crop = the whole volume (or slab) per step; bench.Fit holds the state (fp32 masters, optional 16-bit mirrors: --grid-dtype; --decoder; --precision)"""
+    import bench
+    from neural_image_compression_v2_amd import _lib
+    gdt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.grid_dtype]
+    fit = bench.Fit(dev, dim, method, grid_base=grid_base, shapes=shapes, n_linear=args.decoder, precision=args.precision, grid_dtype=gdt)
     n = int(np.prod(extent))
     g = torch.Generator(device="cpu").manual_seed(1234)
     target = torch.rand(n, 3, generator=g).to(dev)
     org = [list(origin)]
     total = args.warmup + args.steps
-    stream = _lib.stream_ptr(dev)
-    flat = None
 
     def step(i, ev=None):
-        nonlocal flat
-        geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=tuple(extent), num_crops=1,
-                                 noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, split_bf16=args.precision == "split", bf16=args.precision == "bf16")
-        out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], target, flat=flat, events=ev)
-        flat = out.flat
-        _adam(lib, _lib, st, out, i, total, stream)
+        geo = fit.geometry(i, extent, aligned=all(o % 8 == 0 for o in origin))
+        out = fit.fwd_bwd(geo, org, target, ev)
+        fit.adam(out, i, total)
         return out
 
     for i in range(args.warmup):
@@ -103,7 +99,8 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     kms = [a.elapsed_time(b) for a, b in ev]
-    cin, flop, byt = _work(dim, method)
+    gb = 4 if fit.mirror is None else 2
+    cin, flop, byt = bench.work_per_sample(dim, method, args.decoder, gb)
     km = float(np.median(kms))
     unit = "Mvoxels/s" if dim == 3 else "Mpixels/s"
     gbs = byt * n / (km * 1e-3) / 1e9
@@ -113,11 +110,12 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
             "vs_baseline": None, "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate"
                                            if (args.precision == "split" and dim == 3) else _DT[args.precision]),
             "data": "synthetic",
-            "config": {"workload": name, "samples_per_step": n, "extent": list(extent), "grids": [list(st["g0"].shape), list(st["g1"].shape)],
+            "config": {"workload": name, "samples_per_step": n, "extent": list(extent), "grids": [list(g_.shape) for g_ in fit.master],
+                       "grid_storage": args.grid_dtype + (" (fp32 masters + Adam state)" if fit.mirror is not None else ""), "decoder_linear_layers": args.decoder,
                        "method": method, "cin": cin, "final_loss": round(float(out.loss), 6)},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "traffic": None, "kernel_ms": round(km, 4), "stats": _pct(kms), "bytes_per_sample": byt, "flop_per_sample": flop,
-                         "samples_per_launch": n,
+                         "samples_per_launch": n, "kernel": bench.kernel_name(dim, method, args.precision, args.decoder),
                          **({"note": "above 1: SURVEY 8d's byte count assumes no reuse at all; neighbouring samples share their corners (64 samples per G0 cell), "
                                      "the grids sit in L2 / Infinity Cache and the kernel no longer pays those bytes - the figure stops being a bound here"} if gbs > PEAK_HBM_GBS else {}),
                          "mfma_f32_equivalent": {"achieved": round(tfl, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",

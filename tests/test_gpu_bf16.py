@@ -582,3 +582,28 @@ def test_restricted_workgroup_counts_match_the_unrestricted_launch(dev, kind):
             assert relmax(a, b) <= 2e-5, (kind, mw)
         assert relmax(r.grad_g0, full.grad_g0) <= 1e-5 and relmax(r.grad_g1, full.grad_g1) <= 1e-5, (kind, mw)
     assert torch.equal(run(3).loss, run(8).loss), "fewer than 8 workgroups means 8"
+
+
+def test_config_3_lut_at_full_size_fp16_grids(dev):
+    """BASELINE config 3 as stated: a 33^3 colour LUT (RGB -> RGB), the trilinear grid path (method 3, the reference's permuted weights), fp16
+    parameters: one crop of 35 937 samples, grids 10^3 and 6^3 in float16 storage, plain-bf16 products - the whole step against the emulating
+    oracle (small enough for it end to end), and the same step in split products on the widened grids against the fp32 oracle."""
+    from neural_image_compression_v2_amd import _lib, fused
+    g = torch.Generator().manual_seed(44)
+    lo, hi = O.q_range(8)
+    g0 = ((hi - lo) * torch.rand(12, 10, 10, 10, generator=g) + lo).to(torch.float16)
+    g1 = ((hi - lo) * torch.rand(12, 6, 6, 6, generator=g) + lo).to(torch.float16)
+    mlp = O.init_mlp(127, 64, generator=g)
+    ext, org = (33, 33, 33), [(0, 0, 0)]
+    n = 33 ** 3
+    # a smooth colour transform as the target: identity + 0.1 sin warp (SURVEY 8d, config 3)
+    u = torch.linspace(0, 1, 33)
+    r, gg, b = torch.meshgrid(u, u, u, indexing="ij")
+    target = torch.stack([(c + 0.1 * torch.sin(6.28 * d)).clamp(0, 1) for c, d in ((r, gg), (gg, b), (b, r))], -1).reshape(-1, 3).contiguous()
+    noise = O.kernel_noise(n, 127, 8, seed=5, offset=1, quarter=True)
+    ref = O.forward_backward(g0.float(), g1.float(), mlp, org, ext, 0.25, 0, target, noise, 6, method=3, emulate="bf16")
+    ref32 = O.forward_backward(g0.float(), g1.float(), mlp, org, ext, 0.25, 0, target, noise, 6, method=3)
+    geo = fused.PathGeometry(dim=3, method=3, step_number=0.25, mip_level=0, extent=ext, num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=5,
+                             noise_offset=1, bf16=True)
+    out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), org, [q.to(dev) for q in mlp.tensors()], target.to(dev), want_y=True)
+    check_step(out, ref, ref32, 3, "config 3: 33^3 LUT, fp16 grids")
