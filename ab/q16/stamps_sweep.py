@@ -28,7 +28,7 @@ REC = 8 * NACC * 1024 + (8 * 256 if method == 4 else 0) + 8 * (64 + 192 + 4)
 NWG = 256
 off = NWG * REC * 4
 st = ws[off:off + NWG * 8 * 16 * 8].view(torch.int64).view(NWG * 8, 16).cpu().numpy().astype(np.float64)
-names = {0: "encode + noise", 1: "forward", 2: "dW_out, dA_last", 3: "phase 0 compute", 4: "phase 0 barrier + dW", 11: "dX + grid sums", 12: "unit setup + gather", 13: "flush (combine, group sum, atomics)",
+names = {9: "prologue: W1 image", 7: "prologue: hidden + output images", 8: "prologue: biases", 5: "prologue: zeroing", 6: "prologue: barrier + accumulators", 10: "record writes", 0: "encode + noise", 1: "forward", 2: "dW_out, dA_last", 3: "phase 0 compute", 4: "phase 0 barrier + dW", 11: "dX + grid sums", 12: "unit setup + gather", 13: "flush (combine, group sum, atomics)",
          14: "barrier + dW1", 15: "round-end barrier"}
 tot = st.sum(1)
 print(f"method {method}: total cycles per wave median {np.median(tot):.0f} = {np.median(tot) / 2.4e3:.1f} us at 2.4 GHz (min {tot.min():.0f}, max {tot.max():.0f})")

@@ -136,7 +136,10 @@ int64_t wg_cap(int per_cu, int max_wg) {
 #ifndef NIC_RG_MAX_SEG
 #define NIC_RG_MAX_SEG 4
 #endif
-void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false, bool allow_seg0 = false, int rg0_max = NIC_RG_MAX) {
+#ifndef NIC_Q16_RG0
+#define NIC_Q16_RG0 0        // measured: 8-group segment 0 (12 rounds + 2 unit overheads instead of 3) changes nothing on the 3D sweep step (209.5 against 205.5 us, 155.8 against 154)
+#endif
+void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_seg = false, bool allow_seg0 = false, int rg0_max = NIC_RG_MAX, int q0_max = 0) {
     const int64_t waves = wg_cap(per_cu, p.d.max_workgroups) * waves_per_wg;
     const int rounds = p.niter * p.passes;                // niter is a power of two: the groups stay equal with any number of passes
     p.rg_log2 = 0;
@@ -144,11 +147,28 @@ void balance_units(FusedParams& p, int per_cu, int waves_per_wg = 4, bool two_se
     p.seg_split = 0;
     double best = 0.0;
     if (two_seg) {
-        p.seg_split = p.n_tiles / waves * waves;
-        const int64_t rest = p.n_tiles - p.seg_split;
-        for (int rg = 0; rg <= NIC_RG_MAX_SEG && (p.niter >> rg) >= 1 && rest > 0; ++rg) {
-            const double cost = (double)(((rest << rg) + waves - 1) / waves) * ((double)(rounds >> rg) + 0.8);
-            if (rg == 0 || cost < best * 0.98) { best = cost; p.rg_log2 = rg; }
+        // fused_train16: segment 0 = whole units (q0_max = 0).  fused_q16 (q0_max = NIC_Q16_RG0: 8 groups - a macro-tile's groups then fill one
+        // workgroup round and flush twice, once per half): segment 0 may be dealt out in groups as well, when that fills every wave once more -
+        // the reference's 3D sweep step (8 x 46 packed macro-tiles x 64 rounds on 2 048 waves) runs as 256 macro-tiles in 8-round units + 112
+        // in 4-round units = 12 rounds and TWO unit overheads per wave instead of three 4-round units (setup + gather + flush of a unit cost
+        // those kernels 1.3 - 1.5 rounds: stamps 9 - 13 K + 13 - 14 K cycles against 17 K).
+        const double oh = q0_max > 0 ? 1.3 : 0.8;
+        auto rest_cost = [&](int64_t rest, int& rg_best) {
+            double bc = 0.0;
+            rg_best = 0;
+            for (int rg = 0; rg <= NIC_RG_MAX_SEG && (p.niter >> rg) >= 1 && rest > 0; ++rg) {
+                const double cost = (double)(((rest << rg) + waves - 1) / waves) * ((double)(rounds >> rg) + oh);
+                if (rg == 0 || cost < bc * 0.98) { bc = cost; rg_best = rg; }
+            }
+            return bc;
+        };
+        for (int rg0 = 0; rg0 <= q0_max && (p.niter >> rg0) >= 1; ++rg0) {
+            const int64_t full = (p.n_tiles << rg0) / waves;
+            if (rg0 > 0 && full == 0) continue;
+            const int64_t t0 = (full * waves) >> rg0, rest = p.n_tiles - t0;
+            int r1 = 0;
+            const double cost = (double)full * ((double)(rounds >> rg0) + oh) + rest_cost(rest, r1);
+            if (rg0 == 0 || cost < best * 0.98) { best = cost; p.seg_split = t0; p.rg0_log2 = rg0; p.rg_log2 = r1; }
         }
         return;
     }
@@ -390,7 +410,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
     // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes: the reference's 3D sweep shape 0.368 -> 0.332 ms with
     //  method 4; method 3, twice the sums per lane, lost 5 % until its flush pre-added neighbouring sums and gains 6 % since)
-    balance_units(p, 1, wpw, (t16 || q16) && two_seg, !t16 && !q16 && !mlpn && two_seg, NIC_RG_SEG0);
+    balance_units(p, 1, wpw, (t16 || q16) && two_seg, !t16 && !q16 && !mlpn && two_seg, NIC_RG_SEG0, q16 ? NIC_Q16_RG0 : 0);
     const int64_t units0 = p.seg_split << p.rg0_log2, units1 = (p.n_tiles - p.seg_split) << p.rg_log2;
     const int64_t units_max = units0 > units1 ? units0 : units1;
     if (units_max >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;                    // the kernels count work units in 32 bits

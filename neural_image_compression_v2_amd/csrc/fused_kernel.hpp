@@ -355,17 +355,49 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // chosen by a bit triple (see g1_ref_weight_bits): fx[bit], fy[bit], fz[bit].  NIC_G1_UNWEIGHTED (the
 // reference's step_number == 2 case) is the same arithmetic with every factor = 1, which is bit-identical
 // to not multiplying.  Everything here is selects on launch-uniform flags: no branches in the tile loop.
-struct G1Factors {
+// c ? a1 : a0 for two values LOADED from one struct (a local one, or the kernel arguments): written as a plain select, the optimiser folds it into
+// ONE load with a computed offset - which keeps a local struct in memory (scratch, or "promoted" to LDS) and makes every thread copy a by-value
+// kernel-argument struct to scratch first (method 4's plain-bf16 kernels: 632 bytes per thread).  The empty asm hides the loads from that fold.
+__device__ __forceinline__ float pick_loaded(bool c, float a1, float a0) {
+    asm("" : "+v"(a1));
+    asm("" : "+v"(a0));
+    return c ? a1 : a0;
+}
+// (not "if (__builtin_constant_p(c)) return c ? a1 : a0;" for the 2D kernels, whose corner bits are compile-time constants: with it the 2D split
+//  inference kernel returned outputs that changed from run to run by 1e-3 - the callers say which form they need instead)
+
+template <int DIM>
+struct G1FactorsT;
+template <>
+struct G1FactorsT<2> {          // the corner bits are compile-time constants: every select below folds away
     float fx[2], fy[2], fz[2];
     uint32_t bits;          // 3 bits per corner q: bx | by<<1 | bz<<2
 };
+template <>
+struct G1FactorsT<3> {
+    // 3D: the weight mode - the bits - is a launch parameter.  Separate members and pick_loaded, not float[2] and a plain select: "b ? f[1] : f[0]" is
+    // folded into an indexed load f[b], which keeps the struct in memory - the 3D kernels then carried it in LDS (28 bytes per thread: "promote
+    // alloca to LDS"; in scratch where the LDS was full) and, for the flat thread id that addressing needs, read the workgroup size from the dispatch
+    // packet in HOST memory at every launch (stamps: 20 K cycles of the method-3 prologue)
+    float fx0, fx1, fy0, fy1, fz0, fz1;
+    uint32_t bits;
+    __device__ __forceinline__ float x(uint32_t b) const { return pick_loaded((b & 1u) != 0, fx1, fx0); }
+    __device__ __forceinline__ float y(uint32_t b) const { return pick_loaded((b & 2u) != 0, fy1, fy0); }
+    __device__ __forceinline__ float z(uint32_t b) const { return pick_loaded((b & 4u) != 0, fz1, fz0); }
+};
 template <int DIM>
-__device__ __forceinline__ G1Factors g1_factors(int mode, float kx, float ky, float kz) {
-    G1Factors f;
+__device__ __forceinline__ G1FactorsT<DIM> g1_factors(int mode, float kx, float ky, float kz) {
+    G1FactorsT<DIM> f;
     const bool unw = mode == NIC_G1_UNWEIGHTED;
-    f.fx[0] = unw ? 1.0f : 1.0f - kx; f.fx[1] = unw ? 1.0f : kx;
-    f.fy[0] = unw ? 1.0f : 1.0f - ky; f.fy[1] = unw ? 1.0f : ky;
-    f.fz[0] = unw ? 1.0f : 1.0f - kz; f.fz[1] = unw ? 1.0f : kz;
+    if constexpr (DIM == 2) {
+        f.fx[0] = unw ? 1.0f : 1.0f - kx; f.fx[1] = unw ? 1.0f : kx;
+        f.fy[0] = unw ? 1.0f : 1.0f - ky; f.fy[1] = unw ? 1.0f : ky;
+        f.fz[0] = unw ? 1.0f : 1.0f - kz; f.fz[1] = unw ? 1.0f : kz;
+    } else {
+        f.fx0 = unw ? 1.0f : 1.0f - kx; f.fx1 = unw ? 1.0f : kx;
+        f.fy0 = unw ? 1.0f : 1.0f - ky; f.fy1 = unw ? 1.0f : ky;
+        f.fz0 = unw ? 1.0f : 1.0f - kz; f.fz1 = unw ? 1.0f : kz;
+    }
     // corner offsets: 2D q -> (dx = q>>1, dy = q&1); 3D q -> (dx = q>>2, dy = (q>>1)&1, dz = q&1)
     constexpr uint32_t nat2 = (0u) | (2u << 3) | (1u << 6) | (3u << 9);
     constexpr uint32_t nat3 = (0u) | (4u << 3) | (2u << 6) | (6u << 9) | (1u << 12) | (5u << 15) | (3u << 18) | (7u << 21);
@@ -374,16 +406,21 @@ __device__ __forceinline__ G1Factors g1_factors(int mode, float kx, float ky, fl
     return f;
 }
 template <int DIM>
-__device__ __forceinline__ float g1_corner_factor(const G1Factors& f, int q) {      // d(blend)/d(corner q)
+__device__ __forceinline__ float g1_corner_factor(const G1FactorsT<DIM>& f, int q) {      // d(blend)/d(corner q)
     const uint32_t b = (f.bits >> (3 * q)) & 7u;
-    float w = ((b & 1u) ? f.fx[1] : f.fx[0]) * ((b & 2u) ? f.fy[1] : f.fy[0]);
-    if (DIM == 3) w *= (b & 4u) ? f.fz[1] : f.fz[0];
-    return w;
+    if constexpr (DIM == 2) {
+        float w = ((b & 1u) ? f.fx[1] : f.fx[0]) * ((b & 2u) ? f.fy[1] : f.fy[0]);
+        return w;
+    } else {
+        float w = f.x(b) * f.y(b);
+        w *= f.z(b);
+        return w;
+    }
 }
 // blend of one channel: ((g * fx) * fy) (* fz), corners added left to right (fp_def.py:141-144, 176-183;
 // image_compression.py:95) with individually rounded products and sums
 template <int DIM>
-__device__ __forceinline__ float g1_blend(const float* pc, const GridView& g, const G1Factors& f) {
+__device__ __forceinline__ float g1_blend(const float* pc, const GridView& g, const G1FactorsT<DIM>& f) {
     constexpr int K1 = DIM == 2 ? 4 : 8;
     float sum = 0.f;
 #pragma unroll
@@ -391,9 +428,14 @@ __device__ __forceinline__ float g1_blend(const float* pc, const GridView& g, co
         const int dx = DIM == 2 ? (q >> 1) : ((q >> 2) & 1), dy = DIM == 2 ? (q & 1) : ((q >> 1) & 1), dz = DIM == 2 ? 0 : (q & 1);
         const uint32_t b = (f.bits >> (3 * q)) & 7u;
         float v = pc[g.at(dx, dy, dz)];
-        v = mul_rn(v, (b & 1u) ? f.fx[1] : f.fx[0]);
-        v = mul_rn(v, (b & 2u) ? f.fy[1] : f.fy[0]);
-        if (DIM == 3) v = mul_rn(v, (b & 4u) ? f.fz[1] : f.fz[0]);
+        if constexpr (DIM == 2) {
+            v = mul_rn(v, (b & 1u) ? f.fx[1] : f.fx[0]);
+            v = mul_rn(v, (b & 2u) ? f.fy[1] : f.fy[0]);
+        } else {
+            v = mul_rn(v, f.x(b));
+            v = mul_rn(v, f.y(b));
+            v = mul_rn(v, f.z(b));
+        }
         sum = q == 0 ? v : add_rn(sum, v);
     }
     return sum;
@@ -555,7 +597,7 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
     }
     __builtin_amdgcn_sched_barrier(0);
     // --- G1 blend with the reference's factor order
-    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+    const G1FactorsT<D> gf = g1_factors<D>(d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
 #pragma unroll
     for (int cc = 0; cc < kC / 2; ++cc) {
         float sum = 0.f;
@@ -563,9 +605,14 @@ __device__ __forceinline__ void encode_slots(const FusedParams& p, const int (&q
         for (int q = 0; q < K1; ++q) {
             const uint32_t b = (gf.bits >> (3 * q)) & 7u;
             float v = g1v[q * (kC / 2) + cc];
-            v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
-            v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
-            if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
+            if constexpr (D == 2) {
+                v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+                v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+            } else {
+                v = mul_rn(v, gf.x(b));
+                v = mul_rn(v, gf.y(b));
+                v = mul_rn(v, gf.z(b));
+            }
             sum = q == 0 ? v : add_rn(sum, v);
         }
         xs[NG0 + cc] = sum;
@@ -673,7 +720,7 @@ __device__ __forceinline__ void accumulate_grid_grads(const FusedParams& p, cons
     constexpr int NG0 = GridAcc<L>::NG0, K1 = GridAcc<L>::K1;
 #pragma unroll
     for (int s = 0; s < NG0; ++s) ga.g0[s] = s < carried ? dxacc[s >> 4][s & 15] : ga.g0[s] + dxacc[s >> 4][s & 15];   // carried: the tile already holds the sum
-    const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
+    const G1FactorsT<D> gf = g1_factors<D>(p.d.g1_weight_mode, cx.kx, cx.ky, cx.kz);
 #pragma unroll
     for (int q = 0; q < K1; ++q) {
         const float w = g1_corner_factor<D>(gf, q);

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                         return af;
                     });
                 }
-                const G1Factors gf = g1_factors<2>(p.d.g1_weight_mode, kx1, ky1, 0.f);
+                const G1FactorsT<2> gf = g1_factors<2>(p.d.g1_weight_mode, kx1, ky1, 0.f);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const float w = g1_corner_factor<2>(gf, c4);

@@ -318,7 +318,7 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
                 v = tri_pe_row(c, r, Q::P);
             } else {
                 const int k = r >> 1;
-                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : (k == 2 ? d.pe_div[2] : d.pe_div[3]));
+                const float dv = pick_loaded(k == 0, d.pe_div[0], pick_loaded(k == 1, d.pe_div[1], pick_loaded(k == 2, d.pe_div[2], d.pe_div[3])));
                 float sv, cv;
                 sincos_cw(mul_rn(c, dv), sv, cv);
                 v = (r & 1) ? cv : sv;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
                 const int U = u < 2 ? 2 * g + u : 8;
                 const int dm = U >= 6 ? 2 : (U >= 3 ? 1 : 0), k = U - 3 * dm;
                 const float c = dm == 0 ? ax.t1 : (dm == 1 ? ay.t1 : az.t1);
-                const float dv = k == 0 ? d.pe_div[0] : (k == 1 ? d.pe_div[1] : d.pe_div[2]);
+                const float dv = pick_loaded(k == 0, d.pe_div[0], pick_loaded(k == 1, d.pe_div[1], d.pe_div[2]));
                 float sv, cv;
                 sincos_cw(mul_rn(c, dv), sv, cv);
                 if (u < 2) { xs[T0 + 2 * u] = sv; xs[T0 + 2 * u + 1] = cv; }
@@ -357,7 +357,7 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
         }
     }
     // ---- G1 blend with the reference's factor order (fp_def.py:141-144, 176-183, 215-222)
-    const G1Factors gf = g1_factors<D>(d.g1_weight_mode, kf[0], kf[1], kf[2]);
+    const G1FactorsT<D> gf = g1_factors<D>(d.g1_weight_mode, kf[0], kf[1], kf[2]);
 #pragma unroll
     for (int cc = 0; cc < Q::GQ; ++cc) {
         float sum = 0.f;
@@ -365,9 +365,14 @@ __device__ __forceinline__ void encode_q(const FusedParams& p, const int (&q)[3]
         for (int c8 = 0; c8 < Q::K1; ++c8) {
             const uint32_t b = (gf.bits >> (3 * c8)) & 7u;
             float v = raw.g1[c8 * Q::GQ + cc];
-            v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
-            v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
-            if (D == 3) v = mul_rn(v, (b & 4u) ? gf.fz[1] : gf.fz[0]);
+            if constexpr (D == 2) {
+                v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+                v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+            } else {
+                v = mul_rn(v, gf.x(b));
+                v = mul_rn(v, gf.y(b));
+                v = mul_rn(v, gf.z(b));
+            }
             sum = c8 == 0 ? v : add_rn(sum, v);
         }
         xs[I::NG0V + cc] = sum;
@@ -489,6 +494,7 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #define NIC_Q16_SB __builtin_amdgcn_sched_barrier(0)
 #endif
 
+
 // =====================================================================================================
 #ifdef NIC_Q16_NVGPR
 #define NIC_Q16_ATTR __attribute__((amdgpu_waves_per_eu(NIC_Q16_NVGPR, NIC_Q16_NVGPR)))      // diagnostic: how many registers does the kernel really need?
@@ -530,6 +536,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NIC_STAMPS
+    unsigned long long stamp_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
+#endif
 
     // ---------------- prologue: bf16 weight images, fp32 biases, wave regions zeroed
     stage_all<kH * LD1, 512>(tid,
@@ -540,6 +550,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             return ch >= 0 ? v : 0.f;                                   // the constant-one column stays zero: b1 is added in fp32
         },
         [&](int idx, float v) { sm[S::OFF_W1 + idx] = (__bf16)v; });
+#ifdef NIC_STAMPS
+    unsigned long long stamp_t1, stamp_t2;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t1)::"memory");
+#endif
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
         const float* Wk = p.W[1 + k];
@@ -557,11 +571,21 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             return (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
         },
         [&](int idx, float v) { sm[S::OFF_WO + idx] = (__bf16)v; });
+#ifdef NIC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t2)::"memory");
+#endif
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);
     for (int idx = tid; idx < (NH + 1) * kH; idx += 512) Bs[idx] = p.b[idx / kH][idx % kH];
     if (tid < 4) Bs[(NH + 1) * kH + tid] = tid < 3 ? p.b[NL - 1][tid] : 0.f;
+#ifdef NIC_STAMPS
+    unsigned long long stamp_t3, stamp_t4;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t3)::"memory");
+#endif
     if (TRAIN)
         for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
+#ifdef NIC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t4)::"memory");
+#endif
     __syncthreads();
 
     // ---------------- launch-lifetime accumulators: the weight-gradient tiles this wave owns
@@ -584,13 +608,14 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     for (int i = 0; i < NIC_NPH; ++i) stamp_sum[i] = 0;
     unsigned long long stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    if (NL == 3) { stamp_sum[9] = stamp_t1 - stamp_t0; stamp_sum[7] = stamp_t2 - stamp_t1; stamp_sum[8] = stamp_t3 - stamp_t2; stamp_sum[5] = stamp_t4 - stamp_t3; stamp_sum[6] = stamp_last - stamp_t4; }      // 9: prologue; 5 / 6: absolute start / end of the wave (3 layers: phases 5 .. 10 are free)
 #endif
     // ---------------- XCD-aware persistent walk, workgroup-synchronous rounds of 8 units (one per wave), two segments: fused_train16.hpp
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
   for (int seg = 0; seg < 2; ++seg) {
     const int seg_tile0 = seg ? (int)p.seg_split : 0;
     const int seg_tiles = seg ? (int)p.n_tiles - (int)p.seg_split : (int)p.seg_split;
-    const int rg = seg ? p.rg_log2 : 0;
+    const int rg = seg ? p.rg_log2 : p.rg0_log2;
     if (seg_tiles <= 0) continue;                                       // launch-uniform
     const int n_units = seg_tiles << rg;
     const int chunk = (((n_units + 7) >> 3) + 7) & ~7;
@@ -975,7 +1000,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     });
                 }
                 // G1 slots I::NG0V .. + GQ - 1: registers of tile NG0T (and the next one when GQ = 4 .. never: NG0V is a multiple of 4, GQ <= 4)
-                const G1Factors gf = g1_factors<D>(p.d.g1_weight_mode, kf[0], kf[1], kf[2]);
+                const G1FactorsT<D> gf = g1_factors<D>(p.d.g1_weight_mode, kf[0], kf[1], kf[2]);
 #pragma unroll
                 for (int c8 = 0; c8 < Q::K1; ++c8) {
                     const float w = g1_corner_factor<D>(gf, c8);
@@ -1118,11 +1143,20 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     }  // macro-tile loop
   }  // segments
 #ifdef NIC_STAMPS
-    if (lane == 0) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 8 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
+    auto dump_stamps = [&]() {
+        if (NL == 3) {
+            __builtin_amdgcn_s_waitcnt(0);                                      // the record stores have left
+            unsigned long long t_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+            stamp_sum[10] = t_ - stamp_last;
+        }
+        if (lane == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partials + (size_t)gridDim.x * S::REC) + ((size_t)blockIdx.x * 8 + wave) * 16;   // behind the records (nic_workspace_bytes leaves 1 MiB)
 #pragma unroll
-        for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
-    }
+            for (int i = 0; i < NIC_NPH; ++i) dst[i] = stamp_sum[i];
+        }
+    };
+    if (!TRAIN) dump_stamps();
 #endif
 
     if (!TRAIN) return;
@@ -1150,6 +1184,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
         for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
         if (lane == 0) tail[NH * 64 + 192 + c] = v;
     }
+#ifdef NIC_STAMPS
+    dump_stamps();
+#endif
 }
 
 // =====================================================================================================

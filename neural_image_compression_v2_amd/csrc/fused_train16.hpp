@@ -196,7 +196,7 @@ __device__ __forceinline__ void encode16(const FusedParams& p, const int (&q)[3]
         xs[18] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
     }
     // --- G1 blend with the reference's factor order (fp_def.py:141-144)
-    const G1Factors gf = g1_factors<2>(d.g1_weight_mode, cx.kx, cx.ky, 0.f);
+    const G1FactorsT<2> gf = g1_factors<2>(d.g1_weight_mode, cx.kx, cx.ky, 0.f);
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
         float sum = 0.f;
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                         return a;
                     });
                 }
-                const G1Factors gf = g1_factors<2>(p.d.g1_weight_mode, kx1, ky1, 0.f);
+                const G1FactorsT<2> gf = g1_factors<2>(p.d.g1_weight_mode, kx1, ky1, 0.f);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const float w = g1_corner_factor<2>(gf, c4);
