@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 6
+#define NIC_ABI_VERSION 7
 
 enum {
     NIC_OK = 0,
@@ -136,7 +136,7 @@ typedef struct nic_path_desc {
 typedef struct nic_mlp {
     const float *w[NIC_MAX_LINEAR]; /* [H,Cin], [H,H] x (n_linear - 2), [3,H] */
     const float *b[NIC_MAX_LINEAR]; /* [H], [H] x (n_linear - 2), [3] */
-    int32_t n_linear;               /* 3 (0 means 3) or 5 */
+    int32_t n_linear;               /* 3 (0 means 3) or 5; nic_decoder_general_*: 2 .. NIC_MAX_LINEAR */
     int32_t reserved;
 } nic_mlp;
 
@@ -195,6 +195,19 @@ int nic_decoder_forward(const nic_mlp *mlp, const float *x, int64_t n, int cin, 
  *      (overwritten, not accumulated). */
 int nic_decoder_backward(const nic_mlp *mlp, const float *x, const float *dy, int64_t n, int cin, int hidden,
                          float *dx, const nic_mlp_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- the same decoder for ANY Cin >= 1, HIDDEN_LAYER_CHANNELS >= 1 (var2.py:72) and 2 <= n_linear <= NIC_MAX_LINEAR, on explicit
+ *      inputs: layer-wise LDS-tiled fp32 products (csrc/decoder_general.hip), the route of every flag combination the fused kernels do
+ *      not specialise (ColorDecoder.forward, image_compression.py:54-68, with HIDDEN_LAYER_CHANNELS / FEATURE_PYRAMID_CHANNELS /
+ *      PE_CHANNELS of any value).  The sample axis is walked in chunks; the workspace (nic_decoder_general_workspace_bytes for the same
+ *      n, cin, hidden, n_linear; training = 1 for the backward call) holds one chunk's activations, their GELU derivatives and the
+ *      per-slice weight-gradient sums.  _backward recomputes the forward pass of a chunk itself: x and dy in, dx (may be null) and the
+ *      2 n_linear parameter gradients out (overwritten; null entries are skipped; fixed summation order, bit-stable run to run). */
+size_t nic_decoder_general_workspace_bytes(int64_t n, int cin, int hidden, int n_linear, int training);
+int nic_decoder_general_forward(const nic_mlp *mlp, const float *x, int64_t n, int cin, int hidden, float *y, void *workspace,
+                                size_t workspace_bytes, void *stream);
+int nic_decoder_general_backward(const nic_mlp *mlp, const float *x, const float *dy, int64_t n, int cin, int hidden, float *dx,
+                                 const nic_mlp_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused inference: encode + (optional noise) + decoder.  Replaces finally_decode_input_* + arc_decoder(x)
  *      inside decode_image (image_compression.py:313-345).  y = [N, 3]. */

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnicv2_hip.so")
-SOURCES = ["simple_kernels.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip", "fused_t16.hip", "fused_mlpn.hip", "fused_q1.hip", "fused_q2.hip", "fused_q3.hip", "fused_q4.hip"]
+SOURCES = ["simple_kernels.hip", "decoder_general.hip", "fused_capi.hip", "fused_m1.hip", "fused_m2.hip", "fused_m3.hip", "fused_m4.hip", "fused_t16.hip", "fused_mlpn.hip", "fused_q1.hip", "fused_q2.hip", "fused_q3.hip", "fused_q4.hip"]
 # non-default FEATURE_PYRAMID_CHANNELS / PE_CHANNELS on the plain-bf16 kernels: (layout, C, P), one translation unit each
 SOURCES += [f"fused_qc_{l}_{c}_{p}.hip" for l, c, p in [(1, 4, 6), (1, 8, 6), (1, 16, 6), (1, 12, 4), (1, 12, 8), (2, 4, 6), (2, 8, 6), (2, 16, 6), (2, 12, 4), (2, 12, 8),
                                                          (3, 4, 6), (3, 8, 6), (4, 4, 6), (4, 8, 6), (4, 16, 6)]]

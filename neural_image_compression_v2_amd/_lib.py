@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 6
+NIC_ABI_VERSION = 7
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -96,6 +96,9 @@ SIGNATURES = {
     "nic_lut_gather": (_I, [_P, _I, _I, _P, _L, _L, _P, _P]),
     "nic_decoder_forward": (_I, [_M, _P, _L, _I, _I, _P, _P]),
     "nic_decoder_backward": (_I, [_M, _P, _P, _L, _I, _I, _P, _G, _P, _SZ, _P]),
+    "nic_decoder_general_workspace_bytes": (_SZ, [_L, _I, _I, _I, _I]),
+    "nic_decoder_general_forward": (_I, [_M, _P, _L, _I, _I, _P, _P, _SZ, _P]),
+    "nic_decoder_general_backward": (_I, [_M, _P, _P, _L, _I, _I, _P, _G, _P, _SZ, _P]),
     "nic_fused_forward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_u8": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_backward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _P, _P, _G, _P, _SZ, _P]),
@@ -145,10 +148,18 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+class Unsupported(RuntimeError):
+    """NIC_E_UNSUPPORTED: no specialised kernel for this dim / method / channels / hidden / depth combination (nothing was launched).
+    The host loop answers it with the layer-wise general route (nic_encode + nic_decoder_general_*)."""
+
+
+NIC_E_UNSUPPORTED = -2
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().nic_error_string(int(rc)).decode()
-        raise RuntimeError(f"libnicv2_hip {what} failed: {msg} (code {rc})")
+        raise (Unsupported if rc == NIC_E_UNSUPPORTED else RuntimeError)(f"libnicv2_hip {what} failed: {msg} (code {rc})")
 
 
 def stream_ptr(device: Optional[torch.device] = None) -> ctypes.c_void_p:

@@ -1,0 +1,326 @@
+// ColorDecoder of ANY width and depth on explicit [n, Cin] inputs (image_compression.py:54-68: DECODER_INPUT_CHANNELS and
+// HIDDEN_LAYER_CHANNELS are reference flags, var2.py:72,114-118) - the layer-wise fp32 path behind nic_decoder_general_forward /
+// _backward.  The fused kernels specialise the reference's defaults (H = 64, the listed channel counts, 3 or 5 layers); every other
+// configuration of the reference's flags runs here: one LDS-tiled fp32 product kernel per layer and direction, activations kept in a
+// caller-owned workspace the way autograd keeps them, the sample axis walked in chunks sized to stay in L2 / Infinity Cache.
+//
+//   forward   A_k = gelu(A_{k-1} W_k^T + b_k)  (D_k = gelu'(.) kept when training),  y = sigmoid(A_last W_out^T + b_out)
+//   backward  dZ_out = dy y (1 - y);  dA_{k} = dZ_{k+1} W_{k+1};  dZ_k = dA_k D_k;  dW_k = dZ_k^T A_{k-1};  db_k = column sums of dZ_k
+// Weight gradients: every workgroup sums a slice of the chunk's rows into ITS slot of the workspace (slots accumulate over the chunks,
+// launches of one stream are ordered), one fixed-order reduction at the end: results are bit-stable run to run.
+// Arithmetic: fp32 fmaf chains along the reduction index, GELU / sigmoid of nic_device.hpp (the fused kernels' own).
+#include "nic_device.hpp"
+
+namespace nic {
+namespace general {
+
+constexpr int TM = 64, TN = 64, TK = 16, LDT = TM + 4;
+
+// acc[r][c] += sum over the reduction range [k0, k1) of a(row 4 ty + r, k) * b(col 4 tx + c, k).  la / lb return 0 outside their operand.
+// AFAST / BFAST: consecutive lanes walk the reduction index (the operand is contiguous along it) instead of the row / column index.
+template <bool AFAST, bool BFAST, class LoadA, class LoadB, class Side>
+__device__ __forceinline__ void tile_product(int k0, int k1, LoadA&& la, LoadB&& lb, float (&acc)[4][4], Side&& side) {
+    __shared__ __attribute__((aligned(16))) float As[TK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    for (int kb = k0; kb < k1; kb += TK) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            const int ak = AFAST ? (e & 15) : (e >> 6), ai = AFAST ? (e >> 4) : (e & 63);
+            const int bk = BFAST ? (e & 15) : (e >> 6), bj = BFAST ? (e >> 4) : (e & 63);
+            av[r] = kb + ak < k1 ? la(ai, kb + ak) : 0.f;
+            bv[r] = kb + bk < k1 ? lb(bj, kb + bk) : 0.f;
+        }
+        __syncthreads();                                  // the previous tile has been consumed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            As[AFAST ? (e & 15) : (e >> 6)][AFAST ? (e >> 4) : (e & 63)] = av[r];
+            Bs[BFAST ? (e & 15) : (e >> 6)][BFAST ? (e >> 4) : (e & 63)] = bv[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
+            side(a);
+        }
+    }
+}
+
+enum { ACT_GELU = 0, ACT_SIGMOID = 1, ACT_SIGMOID_BWD = 2 };
+
+// out[i][o] = act(sum_k in[i][k] W[o][k] + bias[o]):  in [m][K], W [N][K], out_a / out_d [m][N]
+template <int ACT>
+__global__ void __launch_bounds__(256) linear_forward_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                             int64_t m, int N, int K, float* __restrict__ out_a, float* __restrict__ out_d,
+                                                             const float* __restrict__ dy) {
+    const int64_t i0 = (int64_t)blockIdx.x * TM;
+    const int j0 = blockIdx.y * TN;
+    float acc[4][4] = {};
+    tile_product<true, true>(0, K,
+        [&](int i, int k) { return i0 + i < m ? in[(i0 + i) * K + k] : 0.f; },
+        [&](int j, int k) { return j0 + j < N ? W[(int64_t)(j0 + j) * K + k] : 0.f; }, acc, [](const float (&)[4]) {});
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + 4 * ty + r;
+        if (i >= m) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + 4 * tx + c;
+            if (j >= N) continue;
+            const float z = acc[r][c] + bias[j];
+            if (ACT == ACT_GELU) {
+                float a, d;
+                gelu_and_grad(z, a, d);
+                out_a[i * N + j] = a;
+                if (out_d) out_d[i * N + j] = d;
+            } else {
+                const float y = sigmoid_f(z);
+                if (ACT == ACT_SIGMOID) out_a[i * N + j] = y;
+                else out_a[i * N + j] = dy[i * N + j] * y * (1.0f - y);         // dZ_out
+            }
+        }
+    }
+}
+
+// out[i][k] = (sum_o dz[i][o] W[o][k]) * (D ? D[i][k] : 1):  dz [m][N], W [N][K], D / out [m][K]
+__global__ void __launch_bounds__(256) linear_backward_input_kernel(const float* __restrict__ dz, const float* __restrict__ W, const float* __restrict__ D,
+                                                                    int64_t m, int N, int K, float* __restrict__ out) {
+    const int64_t i0 = (int64_t)blockIdx.x * TM;
+    const int j0 = blockIdx.y * TN;
+    float acc[4][4] = {};
+    tile_product<true, false>(0, N,
+        [&](int i, int o) { return i0 + i < m ? dz[(i0 + i) * N + o] : 0.f; },
+        [&](int j, int o) { return j0 + j < K ? W[(int64_t)o * K + j0 + j] : 0.f; }, acc, [](const float (&)[4]) {});
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + 4 * ty + r;
+        if (i >= m) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + 4 * tx + c;
+            if (j >= K) continue;
+            out[i * K + j] = D ? acc[r][c] * D[i * K + j] : acc[r][c];
+        }
+    }
+}
+
+// slot[s][o][k] (+)= sum over the rows of slice s of dz[i][o] a[i][k];  slot[s][N K + o] (+)= sum of dz[i][o]:  dz [m][N], a [m][K]
+__global__ void __launch_bounds__(256) linear_backward_weight_kernel(const float* __restrict__ dz, const float* __restrict__ a, int64_t m, int N, int K,
+                                                                     int rows_per_slice, float* __restrict__ slots, int64_t slot_stride, int accumulate) {
+    const int s = blockIdx.x;
+    const int o0 = blockIdx.y * TM, k0 = blockIdx.z * TN;
+    const int64_t r0 = (int64_t)s * rows_per_slice;
+    const int64_t r1 = r0 + rows_per_slice < m ? r0 + rows_per_slice : m;
+    float acc[4][4] = {};
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const bool do_db = blockIdx.z == 0 && tx == 0;
+    if (r0 < r1)
+        tile_product<false, false>(0, (int)(r1 - r0),
+            [&](int i, int r) { return o0 + i < N ? dz[(r0 + r) * N + o0 + i] : 0.f; },
+            [&](int j, int r) { return k0 + j < K ? a[(r0 + r) * K + k0 + j] : 0.f; }, acc,
+            [&](const float (&av)[4]) {
+                if (do_db) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dbacc[r] += av[r];
+                }
+            });
+    float* slot = slots + (int64_t)s * slot_stride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 4 * ty + r;
+        if (o >= N) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + 4 * tx + c;
+            if (k >= K) continue;
+            float* d = slot + (int64_t)o * K + k;
+            *d = accumulate ? *d + acc[r][c] : acc[r][c];
+        }
+        if (do_db) {
+            float* d = slot + (int64_t)N * K + o;
+            *d = accumulate ? *d + dbacc[r] : dbacc[r];
+        }
+    }
+}
+
+// dW[o][k] = sum_s slot[s][o K + k], db[o] = sum_s slot[s][N K + o], fixed order
+__global__ void __launch_bounds__(256) reduce_slots_kernel(const float* __restrict__ slots, int n_slots, int64_t slot_stride, int N, int K,
+                                                           float* __restrict__ dW, float* __restrict__ db) {
+    const int64_t total = (int64_t)N * K + N;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= n_slots; s += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[j] += slots[(int64_t)(s + j) * slot_stride + e];
+        }
+        for (; s < n_slots; ++s) part[0] += slots[(int64_t)s * slot_stride + e];
+        const float v = (part[0] + part[1]) + (part[2] + part[3]);
+        if (e < (int64_t)N * K) { if (dW) dW[e] = v; }
+        else if (db) db[e - (int64_t)N * K] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: the chunk plan and the launches
+// ---------------------------------------------------------------------------------------------------
+struct Plan {
+    int64_t rows;                 // samples per chunk
+    int n_slots, rows_per_slice;  // weight-gradient slices of a chunk
+    int64_t act_floats;           // one [rows][H] activation buffer
+    int64_t off_a, off_d, off_dz, off_slots, slot_stride;
+    int64_t slot_layer[NIC_MAX_LINEAR];
+    int64_t total_floats;
+};
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+inline Plan make_plan(int64_t n, int cin, int H, int NL, bool training) {
+    Plan p = {};
+    const int64_t per_row = (int64_t)(training ? 2 * (NL - 1) + 2 : 2) * (H > 3 ? H : 3);
+    int64_t rows = ((int64_t)64 << 20) / per_row;                     // <= 256 MiB of activations per chunk: L2 / Infinity Cache sized
+    rows = rows / 1024 * 1024;
+    if (rows < 1024) rows = 1024;
+    if (rows > 131072) rows = 131072;
+    if (rows > round_up(n > 0 ? n : 1, 64)) rows = round_up(n > 0 ? n : 1, 64);
+    p.rows = rows;
+    p.act_floats = rows * (H > 3 ? H : 3);
+    p.off_a = 0;
+    p.off_d = p.off_a + (training ? NL - 1 : 2) * p.act_floats;       // inference: two ping-pong buffers, no derivatives
+    p.off_dz = p.off_d + (training ? NL - 1 : 0) * p.act_floats;
+    p.off_slots = p.off_dz + (training ? 2 : 0) * p.act_floats;
+    p.n_slots = (int)((rows + 1023) / 1024);
+    if (p.n_slots > 128) p.n_slots = 128;
+    p.rows_per_slice = (int)round_up((rows + p.n_slots - 1) / p.n_slots, TK);
+    int64_t off = 0;
+    for (int l = 0; l < NL; ++l) {
+        const int K = l == 0 ? cin : H, N = l == NL - 1 ? 3 : H;
+        p.slot_layer[l] = off;
+        off += round_up((int64_t)N * K + N, 4);
+    }
+    p.slot_stride = off;
+    p.total_floats = p.off_slots + (training ? (int64_t)p.n_slots * p.slot_stride : 0);
+    return p;
+}
+
+inline bool mlp_general_ok(const nic_mlp* m, int& NL) {
+    if (!m) return false;
+    NL = m->n_linear == 0 ? 3 : m->n_linear;
+    if (NL < 2 || NL > NIC_MAX_LINEAR) return false;
+    for (int i = 0; i < NL; ++i)
+        if (!m->w[i] || !m->b[i]) return false;
+    return true;
+}
+
+// forward pass of one chunk; training: A_k / D_k of every hidden activation stay in the workspace and the output layer leaves dZ_out in dzout
+inline int forward_chunk(const Plan& p, const nic_mlp* mlp, int NL, const float* x, int64_t m, int cin, int H, float* ws, bool training, float* y,
+                         const float* dy, float* dzout, hipStream_t s) {
+    const dim3 blk(256);
+    const float* in = x;
+    int K = cin;
+    for (int l = 0; l < NL - 1; ++l) {
+        float* a = ws + p.off_a + (training ? l : (l & 1)) * p.act_floats;
+        float* d = training ? ws + p.off_d + l * p.act_floats : nullptr;
+        const dim3 grid((unsigned)((m + TM - 1) / TM), (unsigned)((H + TN - 1) / TN));
+        hipLaunchKernelGGL(linear_forward_kernel<ACT_GELU>, grid, blk, 0, s, in, mlp->w[l], mlp->b[l], m, H, K, a, d, (const float*)nullptr);
+        in = a;
+        K = H;
+    }
+    const dim3 grid((unsigned)((m + TM - 1) / TM), 1u);
+    if (dzout) hipLaunchKernelGGL(linear_forward_kernel<ACT_SIGMOID_BWD>, grid, blk, 0, s, in, mlp->w[NL - 1], mlp->b[NL - 1], m, 3, K, dzout, (float*)nullptr, dy);
+    else hipLaunchKernelGGL(linear_forward_kernel<ACT_SIGMOID>, grid, blk, 0, s, in, mlp->w[NL - 1], mlp->b[NL - 1], m, 3, K, y, (float*)nullptr, (const float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+}  // namespace general
+}  // namespace nic
+
+using namespace nic;
+using namespace nic::general;
+
+extern "C" {
+
+size_t nic_decoder_general_workspace_bytes(int64_t n, int cin, int hidden, int n_linear, int training) {
+    if (n < 0 || cin < 1 || hidden < 1 || n_linear < 2 || n_linear > NIC_MAX_LINEAR) return 0;
+    return (size_t)make_plan(n, cin, hidden, n_linear, training != 0).total_floats * sizeof(float);
+}
+
+int nic_decoder_general_forward(const nic_mlp* mlp, const float* x, int64_t n, int cin, int hidden, float* y, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    int NL = 0;
+    if (!mlp_general_ok(mlp, NL) || !x || !y || !workspace) return NIC_E_NULL;
+    if (n < 0 || cin < 1 || hidden < 1) return NIC_E_ARG;
+    if (n == 0) return NIC_OK;
+    const Plan p = make_plan(n, cin, hidden, NL, false);
+    if (workspace_bytes < (size_t)p.total_floats * sizeof(float)) return NIC_E_WORKSPACE;
+    for (int64_t r0 = 0; r0 < n; r0 += p.rows) {
+        const int64_t m = n - r0 < p.rows ? n - r0 : p.rows;
+        const int rc = forward_chunk(p, mlp, NL, x + r0 * cin, m, cin, hidden, (float*)workspace, false, y + r0 * 3, nullptr, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return NIC_OK;
+}
+
+int nic_decoder_general_backward(const nic_mlp* mlp, const float* x, const float* dy, int64_t n, int cin, int hidden, float* dx,
+                                 const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    int NL = 0;
+    if (!mlp_general_ok(mlp, NL) || !x || !dy || !grads || !workspace) return NIC_E_NULL;
+    if (n <= 0 || cin < 1 || hidden < 1) return NIC_E_ARG;
+    const int H = hidden;
+    const Plan p = make_plan(n, cin, H, NL, true);
+    if (workspace_bytes < (size_t)p.total_floats * sizeof(float)) return NIC_E_WORKSPACE;
+    float* ws = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 blk(256);
+    float* slots = ws + p.off_slots;
+    bool first = true;
+    for (int64_t r0 = 0; r0 < n; r0 += p.rows, first = false) {
+        const int64_t m = n - r0 < p.rows ? n - r0 : p.rows;
+        float* dz_cur = ws + p.off_dz;                     // dZ of the layer at hand: [m][3] for the output layer, [m][H] below
+        float* dz_next = ws + p.off_dz + p.act_floats;
+        int rc = forward_chunk(p, mlp, NL, x + r0 * cin, m, cin, H, ws, true, nullptr, dy + r0 * 3, dz_cur, s);
+        if (rc) return rc;
+        const int n_slices = (int)((m + p.rows_per_slice - 1) / p.rows_per_slice);
+        for (int l = NL - 1; l >= 0; --l) {
+            const int K = l == 0 ? cin : H, N = l == NL - 1 ? 3 : H;
+            const float* a_in = l == 0 ? x + r0 * cin : ws + p.off_a + (l - 1) * p.act_floats;
+            // a chunk with fewer slices than the plan's leaves the other slots untouched: they were written (or zeroed) by the first chunk
+            {
+                const dim3 grid((unsigned)(first ? p.n_slots : n_slices), (unsigned)((N + TM - 1) / TM), (unsigned)((K + TN - 1) / TN));
+                hipLaunchKernelGGL(linear_backward_weight_kernel, grid, blk, 0, s, (const float*)dz_cur, a_in, m, N, K, p.rows_per_slice,
+                                   slots + p.slot_layer[l], p.slot_stride, first ? 0 : 1);
+            }
+            if (l > 0 || dx) {
+                const float* D = l > 0 ? ws + p.off_d + (l - 1) * p.act_floats : nullptr;
+                float* out = l > 0 ? dz_next : dx + r0 * cin;
+                const dim3 grid((unsigned)((m + TM - 1) / TM), (unsigned)((K + TN - 1) / TN));
+                hipLaunchKernelGGL(linear_backward_input_kernel, grid, blk, 0, s, (const float*)dz_cur, mlp->w[l], D, m, N, K, out);
+            }
+            float* t = dz_cur; dz_cur = dz_next; dz_next = t;
+        }
+        { const int e = (int)hipGetLastError(); if (e) return e; }
+    }
+    for (int l = 0; l < NL; ++l) {
+        const int K = l == 0 ? cin : H, N = l == NL - 1 ? 3 : H;
+        if (!grads->w[l] && !grads->b[l]) continue;
+        const int64_t total = (int64_t)N * K + N;
+        const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+        hipLaunchKernelGGL(reduce_slots_kernel, dim3(grid), blk, 0, s, (const float*)(slots + p.slot_layer[l]), p.n_slots, p.slot_stride, N, K, grads->w[l],
+                           grads->b[l]);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

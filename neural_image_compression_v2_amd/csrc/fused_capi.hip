@@ -276,6 +276,7 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.grad_scale = 2.0f * d->loss_scale;
 }
 int mlp_depth(const nic_mlp* m) { return m->n_linear == 0 ? 3 : m->n_linear; }
+bool depth_unsupported(const nic_mlp* m) { const int n = mlp_depth(m); return n != 3 && n != 5 && n >= 2 && n <= NIC_MAX_LINEAR; }
 void fill_mlp(FusedParams& p, const nic_mlp* m) {
     for (int i = 0; i < NIC_MAX_LINEAR; ++i) { p.W[i] = m->w[i]; p.b[i] = m->b[i]; }
     p.n_linear = mlp_depth(m);
@@ -363,6 +364,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
                 void* workspace, size_t workspace_bytes, void* stream, const nic_target_image* img = nullptr) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
+    if (mlp && depth_unsupported(mlp)) return NIC_E_UNSUPPORTED;      // the fused kernels exist for 3 and 5 Linear layers
     int rc = check_geometry(d, true);
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !g0_grad || !g1_grad || !grads || !workspace) return NIC_E_NULL;
@@ -465,6 +467,7 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
                       const float* noise, float* y, void* stream) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
+    if (mlp && depth_unsupported(mlp)) return NIC_E_UNSUPPORTED;      // the fused kernels exist for 3 and 5 Linear layers
     int rc = check_geometry(d);
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
@@ -506,6 +509,7 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
                          float* y, uint8_t* y_u8, void* stream) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
+    if (mlp && depth_unsupported(mlp)) return NIC_E_UNSUPPORTED;      // the fused kernels exist for 3 and 5 Linear layers
     int rc = check_geometry(d);
     if (rc) return rc;
     if (!g0_u8 || !g1_u8 || !origins || !mlp_ok(mlp) || (!y && !y_u8)) return NIC_E_NULL;

@@ -232,8 +232,8 @@ def _grads_struct(grads: Sequence[Optional[torch.Tensor]]) -> _lib.NicMlpGrads:
 
 def check_mlp(params: Sequence[torch.Tensor], cin: int, hidden: int) -> List[torch.Tensor]:
     params = list(params)
-    if len(params) not in (6, 10):
-        raise NotImplementedError("decoders of 3 (the reference, image_compression.py:57-64) or 5 Linear layers")
+    if len(params) % 2 or not 2 <= len(params) // 2 <= _lib.NIC_MAX_LINEAR:
+        raise NotImplementedError(f"decoders of 2 .. {_lib.NIC_MAX_LINEAR} Linear layers (the reference has 3, image_compression.py:57-64)")
     nl = len(params) // 2
     shapes = [(hidden, cin), (hidden,)] + [(hidden, hidden), (hidden,)] * (nl - 2) + [(3, hidden), (3,)]
     names = [f"{k}{i + 1}" for i in range(nl) for k in ("W", "b")]
@@ -632,19 +632,33 @@ def encode_differentiable(geo: PathGeometry, g0, g1, coord) -> torch.Tensor:
     return EncodeFunction.apply(g0, g1, geo, org)
 
 
+def decoder_is_specialised(cin: int, hidden: int, n_linear: int) -> bool:
+    """the reference's defaults (Cin of the three layouts, H = 64, 3 Linear layers) run on the MFMA decoder kernel; every other width /
+    depth on the layer-wise general kernels (csrc/decoder_general.hip)"""
+    return cin in (73, 127, 79) and hidden == 64 and n_linear == 3
+
+
 class DecoderFunction(torch.autograd.Function):
-    """ColorDecoder.forward on an explicit [n, Cin] input (image_compression.py:66-68) and its backward."""
+    """ColorDecoder.forward on an explicit [n, Cin] input (image_compression.py:66-68) and its backward; ``params`` = W1, b1, W2, b2, ..
+    in nn.Sequential order, any Cin / HIDDEN_LAYER_CHANNELS, 2 .. 5 Linear layers."""
 
     @staticmethod
     @_on_tensor_device
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
-        params = check_mlp([w1, b1, w2, b2, w3, b3], x.shape[1], w2.shape[0])
+    def forward(ctx, x, *params):
+        hidden = params[0].shape[0]
+        params = check_mlp(params, x.shape[1], hidden)
         xc = _lib.require_cuda_f32(x, "x")
         n, cin = xc.shape
+        nl = len(params) // 2
         y = torch.empty(n, 3, dtype=torch.float32, device=xc.device)
         m = _mlp_struct(params)
-        _lib.check(_lib.load().nic_decoder_forward(ctypes.byref(m), _lib.ptr(xc), n, cin, w2.shape[0], _lib.ptr(y),
-                                                   _lib.stream_ptr(xc.device)), "nic_decoder_forward")
+        lib = _lib.load()
+        if decoder_is_specialised(cin, hidden, nl):
+            _lib.check(lib.nic_decoder_forward(ctypes.byref(m), _lib.ptr(xc), n, cin, hidden, _lib.ptr(y), _lib.stream_ptr(xc.device)), "nic_decoder_forward")
+        else:
+            ws = _lib.workspace(xc.device, int(lib.nic_decoder_general_workspace_bytes(n, cin, hidden, nl, 0)))
+            _lib.check(lib.nic_decoder_general_forward(ctypes.byref(m), _lib.ptr(xc), n, cin, hidden, _lib.ptr(y), _lib.ptr(ws), ws.numel(),
+                                                       _lib.stream_ptr(xc.device)), "nic_decoder_general_forward")
         ctx.save_for_backward(xc, *params)
         return y
 
@@ -654,13 +668,22 @@ class DecoderFunction(torch.autograd.Function):
         x, *params = ctx.saved_tensors
         dy = _lib.require_cuda_f32(dy, "dy")
         n, cin = x.shape
+        hidden, nl = params[0].shape[0], len(params) // 2
         dev = x.device
         need = ctx.needs_input_grad
         dx = torch.empty_like(x) if need[0] else None
         gm = [torch.empty_like(p) for p in params]
         lib = _lib.load()
-        ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(None)))
         m, gs = _mlp_struct(params), _grads_struct(gm)
-        _lib.check(lib.nic_decoder_backward(ctypes.byref(m), _lib.ptr(x), _lib.ptr(dy), n, cin, params[2].shape[0], _lib.ptr(dx),
-                                            ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_decoder_backward")
-        return (dx, *[gm[i] if need[1 + i] else None for i in range(6)])
+        if n == 0:
+            for g in gm:
+                g.zero_()
+        elif decoder_is_specialised(cin, hidden, nl):
+            ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(None)))
+            _lib.check(lib.nic_decoder_backward(ctypes.byref(m), _lib.ptr(x), _lib.ptr(dy), n, cin, hidden, _lib.ptr(dx),
+                                                ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_decoder_backward")
+        else:
+            ws = _lib.workspace(dev, int(lib.nic_decoder_general_workspace_bytes(n, cin, hidden, nl, 1)))
+            _lib.check(lib.nic_decoder_general_backward(ctypes.byref(m), _lib.ptr(x), _lib.ptr(dy), n, cin, hidden, _lib.ptr(dx),
+                                                        ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_decoder_general_backward")
+        return (dx, *[gm[i] if need[1 + i] else None for i in range(len(gm))])

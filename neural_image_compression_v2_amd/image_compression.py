@@ -30,14 +30,16 @@ from .var2 import Settings
 class ColorDecoder(nn.Module):
     """Linear(Cin,H)-GELU-Linear(H,H)-GELU-Linear(H,3)-Sigmoid (image_compression.py:54-68).  The nn.Sequential only
     owns the parameters (state_dict keys decoder.{0,2,4}.{weight,bias}, default nn.Linear init); forward() runs the
-    whole stack in one HIP kernel (nic_decoder_forward) with its own autograd backward (nic_decoder_backward)."""
+    whole stack in HIP kernels with their own autograd backward: one MFMA kernel (nic_decoder_forward / _backward) for the reference's
+    defaults (Cin 73 / 127 / 79, H = 64, 3 layers), the layer-wise general kernels (nic_decoder_general_*) for every other
+    DECODER_INPUT_CHANNELS / HIDDEN_LAYER_CHANNELS (var2.py:72,114-118) and depth."""
 
     def __init__(self, decoder_input_channels: int = 73, hidden_layer_channels: int = 64, n_linear: int = 3):
         """``n_linear``: 3 = the reference's decoder (depth is hard-coded there); 5 = the "4 x 64" decoder of the north star
-        (keys decoder.{0,2,4,6,8}), served by the fused 2D training step and decode."""
+        (keys decoder.{0,2,4,6,8}); 2 .. 5 accepted."""
         super().__init__()
-        if n_linear not in (3, 5):
-            raise NotImplementedError("3 or 5 Linear layers")
+        if not 2 <= n_linear <= _lib.NIC_MAX_LINEAR:
+            raise NotImplementedError(f"2 .. {_lib.NIC_MAX_LINEAR} Linear layers")
         layers = [nn.Linear(decoder_input_channels, hidden_layer_channels), nn.GELU()]
         for _ in range(n_linear - 2):
             layers += [nn.Linear(hidden_layer_channels, hidden_layer_channels), nn.GELU()]
@@ -49,9 +51,6 @@ class ColorDecoder(nn.Module):
         return [t for m in self.decoder if isinstance(m, nn.Linear) for t in (m.weight, m.bias)]
 
     def forward(self, x):
-        if self.n_linear != 3:
-            raise NotImplementedError("the stand-alone decoder kernel is built for the reference's 3 layers; deeper decoders run inside the "
-                                      "fused step / decode (fused.fused_forward, fused.fused_forward_backward)")
         return fused.DecoderFunction.apply(x, *self.linear_params())
 
 
@@ -219,31 +218,66 @@ class ImageCompression:
             target = inputs.reshape(-1, 3)
         noisy = epoch < c.NUM_EPOCHS * 0.95
         plan_used = None
-        if fused_step and fp[2 * fl].requires_grad:
-            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
-                                 noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
-                                 noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16)
-            if isinstance(target, fused.TargetImage) and not os.environ.get("NIC_NO_PLAN"):
-                # the steady state: one prepared launch plan (and one reused gradient bucket) per (level, LOD)
-                plans = self.__dict__.setdefault("_plans", {})
-                plan = plans.get((fl, lod))
-                lin = self.decoder.linear_params()
-                if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
-                    plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
-                out = plan.run(coord, geo.noise_mode, noise_seed, epoch)
-                plan_used = plan
-            else:
-                flats = self.__dict__.setdefault("_flat", {})      # one gradient bucket per level, reused: the optimiser's launch table stays valid
-                out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl))
-                flats[fl] = out.flat
+        if fused_step and fp[2 * fl].requires_grad and not getattr(self, "_no_fused_kernel", False):
+            try:
+                out, plan_used = self._fused_train_launch(fp, fl, lod, coord, target, noisy, noise_seed, epoch)
+            except _lib.Unsupported:
+                # a flag combination the fused kernels do not specialise (HIDDEN_LAYER_CHANNELS != 64, other channel counts, depths): the
+                # layer-wise route below - nic_encode, the general decoder kernels, nic_encode_backward - serves it from now on
+                self._no_fused_kernel = True
+                if isinstance(target, fused.TargetImage):
+                    target = self._materialise_target(target, coord, lod)
+                return self._train_step_tail(fp, epoch, fl, lod, coord, target, noisy, noise_seed, None, layerwise=True)
             for t in fp:                                           # optimizer.zero_grad(set_to_none=True) without its hooks: the other levels must not step
                 t.grad = None
             fp[2 * fl].grad, fp[2 * fl + 1].grad = out.grad_g0, out.grad_g1
             for p, g in zip(self.decoder.linear_params(), out.grad_mlp):
                 p.grad = g
             loss = out.loss if out.loss.data_ptr() != out.flat.data_ptr() else out.loss.clone()   # a slot of the reused bucket is rewritten by the next step
-        elif c.DECODER_LINEAR_LAYERS != 3:
-            # deeper decoders have no stand-alone kernel: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
+            return self._train_step_tail(fp, epoch, fl, lod, coord, target, noisy, noise_seed, plan_used, loss=loss)
+        if isinstance(target, fused.TargetImage):
+            target = self._materialise_target(target, coord, lod)
+        return self._train_step_tail(fp, epoch, fl, lod, coord, target, noisy, noise_seed, None, layerwise=getattr(self, "_no_fused_kernel", False))
+
+    def _materialise_target(self, target, coord, lod):
+        """[num_crops * n, 3] fp32 targets of the given origins from the resident image (the layer-wise route has no in-kernel target fetch)"""
+        c = self.cfg
+        re_crop = max(1, c.CROP_SIZE // pow(2, lod))
+        coord_h = coord.cpu() if isinstance(coord, torch.Tensor) else coord
+        if getattr(self, "_sampler", None) is not None:
+            return self._crops_rgbx(target, coord_h, re_crop)
+        return self._crops(self.images[lod], coord_h, re_crop)
+
+    def _fused_train_launch(self, fp, fl, lod, coord, target, noisy, noise_seed, epoch):
+        """the fused forward + backward launch of one step; returns (StepOutput, the StepPlan used or None)"""
+        c = self.cfg
+        plan_used = None
+        geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS,
+                             noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE,
+                             noise_seed=noise_seed, noise_offset=epoch, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16)
+        if isinstance(target, fused.TargetImage) and not os.environ.get("NIC_NO_PLAN"):
+            # the steady state: one prepared launch plan (and one reused gradient bucket) per (level, LOD)
+            plans = self.__dict__.setdefault("_plans", {})
+            plan = plans.get((fl, lod))
+            lin = self.decoder.linear_params()
+            if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
+                plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
+            out = plan.run(coord, geo.noise_mode, noise_seed, epoch)
+            plan_used = plan
+        else:
+            flats = self.__dict__.setdefault("_flat", {})      # one gradient bucket per level, reused: the optimiser's launch table stays valid
+            out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl))
+            flats[fl] = out.flat
+        return out, plan_used
+
+    def _train_step_tail(self, fp, epoch, fl, lod, coord, target, noisy, noise_seed, plan_used, loss=None, layerwise=False):
+        """the unfused forms of the step (when ``loss`` is None) and what follows every step: optimiser, scheduler, clamp"""
+        c = self.cfg
+        D = c.FP_DIMENSION
+        if loss is not None:
+            pass
+        elif c.DECODER_LINEAR_LAYERS != 3 and not layerwise:
+            # deeper decoders: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE, noise_seed=noise_seed, noise_offset=epoch)
             y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
@@ -347,8 +381,21 @@ class ImageCompression:
             ga, gb = fp[2 * fl], fp[2 * fl + 1]
             if D == 3 and not stored:
                 ga, gb = ga.detach(), gb.detach()           # 3D decodes read the fp32 masters (the 16-bit mirrors are a training-side storage; 2D decodes gather from them)
-            run = (lambda geo, org: fused.fused_forward_u8(geo, ga, gb, org, params)) if stored else \
-                  (lambda geo, org: fused.fused_forward(geo, ga, gb, org, params))
+            run_fused = (lambda geo, org: fused.fused_forward_u8(geo, ga, gb, org, params)) if stored else \
+                        (lambda geo, org: fused.fused_forward(geo, ga, gb, org, params))
+
+            def run(geo, org):
+                if not getattr(self, "_no_fused_decode", False):
+                    try:
+                        return run_fused(geo, org)
+                    except _lib.Unsupported:
+                        self._no_fused_decode = True       # widths / depths without a fused kernel: encode + the general decoder kernels
+                if stored:
+                    from .fp_def import fp_load
+                    a, b = fp_load([ga, gb], c.FP_BITS, torch.float32)
+                else:
+                    a, b = ga.detach(), gb.detach()
+                return fused.DecoderFunction.apply(fused.encode(geo, a, b, org), *[t.detach() for t in params])
             split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)
             # channel counts other than the reference's defaults exist on the plain-bf16 kernels only: their forward pass decodes
             wide = (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) != (12, 6)

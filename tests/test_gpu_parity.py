@@ -613,15 +613,20 @@ def test_16_bit_grid_storage(dev, dt, nl):
 def test_deep_decoder_module_and_training_loop(dev):
     """ColorDecoder(n_linear = 5): Sequential keys decoder.{0,2,4,6,8}; a short fit through ImageCompression (fused steps, one-launch
     Adam over 10 decoder tensors, freeze / quantise tail through the fused differentiable op, decode + PSNR) against the oracle's
-    loop on the same crops and noise; unsupported combinations fail loudly."""
+    loop on the same crops and noise."""
     import random
     from neural_image_compression_v2_amd import fused
     from neural_image_compression_v2_amd.image_compression import ColorDecoder, ImageCompression
     from neural_image_compression_v2_amd.var2 import Settings
     dec = ColorDecoder(73, 64, 5)
     assert [k for k in dec.state_dict()] == [f"decoder.{i}.{w}" for i in (0, 2, 4, 6, 8) for w in ("weight", "bias")]
+    # the module on an explicit tensor: the layer-wise general kernels (the fused MFMA decoder kernel is the 3-layer one)
+    xe = torch.rand(300, 73, generator=torch.Generator().manual_seed(2)) - 0.5
+    ye = dec.to(dev)(xe.to(dev))
+    mlp_e = O.MLPParams.from_state_dict({k: v.detach().cpu() for k, v in dec.state_dict().items()})
+    assert relmax(ye, O.mlp_forward(xe, mlp_e)) < 1e-5
     with pytest.raises(NotImplementedError):
-        dec.to(dev)(torch.zeros(4, 73, device=dev))
+        ColorDecoder(73, 64, 6)
     cfg = Settings(IMAGE_SIZE=256, NUM_EPOCHS=24, NUM_CROPS=2, TF_NO_MIP=True, DECODER_LINEAR_LAYERS=5)
     S = cfg.IMAGE_SIZE
     gen = torch.Generator().manual_seed(12)

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nicv2_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.nic_abi_version() == _lib.NIC_ABI_VERSION == 6
+    assert lib.nic_abi_version() == _lib.NIC_ABI_VERSION == 7
     assert lib.nic_error_string(-2).decode().startswith("unsupported")
     assert lib.nic_decoder_input_channels(2, 1, 12, 6) == 73          # var2.py:114-118
     assert lib.nic_decoder_input_channels(3, 3, 12, 6) == 127
