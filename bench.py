@@ -598,7 +598,7 @@ def main():
     ap.add_argument("--method", type=int, choices=[3, 4], default=4, help="--workload video: COMPRESSION_METHOD")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
-    ap.add_argument("--workload", default="4k", choices=["4k", "video", "fits64", "lut33", "vol64", "vol128", "slab", "default", "default3d", "fits8"],
+    ap.add_argument("--workload", default="4k", choices=["4k", "video", "fits64", "lut33", "vol64", "vol128", "slab", "default", "default3d", "fits8", "multilevel"],
                     help="4k (default): BASELINE configs[1], the headline; video / fits64: configs 4 / 5 (any --gpus); the others: bench_workloads.py "
                          "(one GPU, same JSON shape - records for profiles/; the driver runs the default only)")
     ap.add_argument("--launch-check", action="store_true",

@@ -10,6 +10,9 @@ records are kept under profiles/.
     slab     config 4, one rank's slab of the 1920 x 1080 x 64 video field (the whole field, any --gpus: bench.py --workload video) (x <-> T, y <-> H, z <-> W; grids [12,481,271,17] +
              [12,241,136,9] at full size): z in [240 r, 240 r + 240), 16.6 Mvox per step, method 4 (and 3)
     default  the reference's default step: IMAGE_SIZE 512, 8 random crops of 256 x 256, through the product's host loop
+    multilevel  config 2's "16-level grid" as the extension it is (multilevel.py: the reference reads ONE level pair per sample): 3840 x 2160,
+             L = 5 level pairs (10 grids, what the reference's halving pyramid holds at this size) concatenated into Cin = 361, "4 x 64" decoder;
+             layer-wise kernels (nic_encode, nic_decoder_general_*, nic_encode_backward, nic_adam_multi), the image walked in chunks
     fits8    config 5, one GPU's share: 8 independent 1080p fits, each with its own grids / decoder / optimiser state and stream -
              concurrently with an eighth of the CUs each (nic_path_desc.max_workgroups) against the same 8 steps back to back
 """
@@ -248,6 +251,48 @@ def _run_fits8(args, dev):
                          "frac": round(byt * res[best]["mpix_s"] * 1e6 / 1e9 / PEAK_HBM_GBS, 4), "traffic": None}}
 
 
+def _run_multilevel(args, dev, levels=5, n_linear=5, chunk=(1024, 540)):
+    """one step = one pass over every pixel of a 3840 x 2160 image in chunks (gradients accumulate, one Adam launch at the end)"""
+    from neural_image_compression_v2_amd.multilevel import MultiLevelField
+    H, W = 2160, 3840
+    f = MultiLevelField((H, W), levels, hidden=64, n_linear=n_linear, device=dev, seed=0)
+    tgt = torch.rand(H, W, 3, device=dev)
+    chunks = [(x0, y0) for x0 in range(0, H, chunk[1]) for y0 in range(0, W, chunk[0])]
+
+    def step():
+        tot = None
+        for k, (x0, y0) in enumerate(chunks):
+            ext = (min(chunk[1], H - x0), min(chunk[0], W - y0))
+            t = tgt[x0:x0 + ext[0], y0:y0 + ext[1]].reshape(-1, 3)
+            l = f.train_step([[x0, y0]], ext, t, noise=True, accumulate=k > 0, scale=ext[0] * ext[1] / (H * W), step=k == len(chunks) - 1)
+            tot = l if tot is None else tot + l
+        return tot
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    px = H * W
+    C, P = 12, 6
+    byt = levels * (8 * C * 4 + 2 * 8 * C * 4) + 3 * 4                      # SURVEY 8d's extended-mode formula: L pairs x (K0 + K1) C x (e_param + 2 e_grad) + target
+    flop = 6 * (f.cin * 64 + (n_linear - 2) * 64 * 64 + 3 * 64)
+    return {"metric": "Mpixels/sec train-step, multi-level extension (layer-wise kernels)", "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3840x2160 RGB fit, every pixel once per step, {levels} level pairs ({2 * levels} grids "
+                                   f"{[list(g.shape) for g in f.fp]}) concatenated: Cin {f.cin}, {n_linear}xLinear(64) decoder, torch.rand noise, MSE, "
+                                   f"{len(chunks)} chunks of {chunk[1]}x{chunk[0]} px, Adam + clamp", "samples_per_step": px, "final_loss": round(float(loss), 6),
+                       "parameters": int(sum(g.numel() for g in f.fp))},
+            "roofline": {"bound": "hbm", "achieved": round(byt * px / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(byt * px / dt / 1e9 / PEAK_HBM_GBS, 4),
+                         "traffic": None, "bytes_per_sample": byt, "flop_per_sample": flop,
+                         "note": "algorithmic bytes of the extended mode; this route MATERIALISES the [N, Cin] input, its gradient and every activation "
+                                 f"(~ {4 * (3 * f.cin + 4 * (n_linear - 1) * 64)} B per sample of real traffic): it is the unfused composition, not a fused kernel"}}
+
+
 def run(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -272,6 +317,8 @@ def run(args):
                 recs.append(_run_default3d(args, dev, method, size))
     elif w == "fits8":
         recs.append(_run_fits8(args, dev))
+    elif w == "multilevel":
+        recs.append(_run_multilevel(args, dev))
     else:
         raise SystemExit(f"unknown workload {w}")
     for r in recs:
