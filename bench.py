@@ -596,6 +596,8 @@ def main():
                          "exchanges the loss, the decoder gradients and one boundary node row per neighbour pair.  replicated: replicated "
                          "parameters, the whole gradient bucket is all-reduced")
     ap.add_argument("--method", type=int, choices=[3, 4], default=4, help="--workload video: COMPRESSION_METHOD")
+    ap.add_argument("--graph", type=int, default=0, help="--workload default / default3d: time replays of a captured hipGraph of this many training steps "
+                                                         "(ImageCompression.train_models_graph) instead of the host loop")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="diagnostic, one process: run rank 0's share of an N-rank stripe-sharded step without the collectives")
     ap.add_argument("--workload", default="4k", choices=["4k", "video", "fits64", "lut33", "vol64", "vol128", "slab", "default", "default3d", "fits8", "multilevel"],

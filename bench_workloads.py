@@ -125,19 +125,13 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
                                                  "frac": round(tfl / PEAK_FP32_MATRIX_TFLOPS, 4)}}}
 
 
-def _run_default(args, dev):
-    """the reference's default step shape through the product's host loop (origins from the reference's RNG calls)"""
-    import random
-    from neural_image_compression_v2_amd.image_compression import ImageCompression
-    from neural_image_compression_v2_amd.var2 import Settings
-    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16")
-    S = cfg.IMAGE_SIZE
-    u = torch.linspace(0, 1, S)
-    img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :] for c in range(3)])
-    ic = ImageCompression(cfg, dev, seed=0)
-    ic.set_images([torch.round(img.clamp(0, 1) * 255).to(torch.uint8)])
-    torch.manual_seed(1)
-    random.seed(1)
+def _time_loop(args, ic, graph):
+    """seconds per step of the product's training loop: the host loop (train_step per step), or - graph > 0 - replays of a captured hipGraph of
+    `graph` steps (train_models_graph: origins, noise offset, Adam step and learning rate from device memory)"""
+    if graph:
+        ic.train_models_graph(ic.feature_pyramid, steps_per_graph=graph, time_replays=True)
+        t = ic.graph_timing
+        return t["seconds"] / t["steps"], t["steps"], f"hipGraph replays of {graph} captured steps, no host work per step"
     for e in range(args.warmup):
         ic.train_step(ic.feature_pyramid, e)
     torch.cuda.synchronize()
@@ -145,11 +139,30 @@ def _run_default(args, dev):
     for e in range(args.warmup, args.warmup + args.steps):
         ic.train_step(ic.feature_pyramid, e)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    return (time.perf_counter() - t0) / args.steps, args.steps, "host loop included"
+
+
+def _run_default(args, dev):
+    """the reference's default step shape through the product's host loop (origins from the reference's RNG calls)"""
+    import random
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    graph = int(getattr(args, "graph", 0) or 0)
+    n_ep = args.warmup + args.steps + 1 if not graph else int(math.ceil((1 + graph * (1 + (args.warmup + args.steps) // graph)) / 0.95)) + 1
+    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=n_ep, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16",
+                   TF_DEVICE_SAMPLER=bool(graph))
+    S = cfg.IMAGE_SIZE
+    u = torch.linspace(0, 1, S)
+    img = torch.stack([0.5 + 0.25 * torch.sin(2 * math.pi * (c + 1) * u)[:, None] * torch.cos(2 * math.pi * (c + 2) * u)[None, :] for c in range(3)])
+    ic = ImageCompression(cfg, dev, seed=0)
+    ic.set_images([torch.round(img.clamp(0, 1) * 255).to(torch.uint8)])
+    torch.manual_seed(1)
+    random.seed(1)
+    dt, steps, how = _time_loop(args, ic, graph)
     px = cfg.NUM_CROPS * 256 * 256
     cin, flop, byt = _work(2, 1)
-    return {"metric": "Mpixels/sec train-step, the reference's default 8 x 256^2 random-crop step (host loop included)", "value": round(px / dt / 1e6, 2),
-            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
+    return {"metric": f"Mpixels/sec train-step, the reference's default 8 x 256^2 random-crop step ({how})", "value": round(px / dt / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": _DT[args.precision], "data": "synthetic",
             "config": {"workload": "IMAGE_SIZE 512, 8 random crops of 256 x 256 per step (var2.py defaults), targets from the resident uint8 image, "
                                    "one-launch Adam", "samples_per_step": px, "psnr_db": round(float(ic.psnr(ic.feature_pyramid)), 3)},
@@ -163,26 +176,21 @@ def _run_default3d(args, dev, method, size):
     import random
     from neural_image_compression_v2_amd.image_compression import ImageCompression
     from neural_image_compression_v2_amd.var2 import Settings
+    graph = int(getattr(args, "graph", 0) or 0)
     cfg = Settings(IMAGE_SIZE=size, IMAGE_3D_SIZE=size, IMAGE_DIMENSION=3, COMPRESSION_METHOD=method, CROP_MIP_LEVEL=5,
-                   NUM_EPOCHS=args.warmup + args.steps + 1, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16")
+                   NUM_EPOCHS=(args.warmup + args.steps + 1 if not graph else int(math.ceil((1 + graph * (1 + (args.warmup + args.steps) // graph)) / 0.95)) + 1),
+                   TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16", TF_DEVICE_SAMPLER=bool(graph))
     g = torch.Generator(device="cpu").manual_seed(5)
     vol = torch.randint(0, 256, (3, size, size, size), generator=g, dtype=torch.uint8)
     ic = ImageCompression(cfg, dev, seed=0)
     ic.set_images([vol], den=256.0)
     torch.manual_seed(1)
     random.seed(1)
-    for e in range(args.warmup):
-        ic.train_step(ic.feature_pyramid, e)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for e in range(args.warmup, args.warmup + args.steps):
-        ic.train_step(ic.feature_pyramid, e)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt, steps, how = _time_loop(args, ic, graph)
     n = cfg.NUM_CROPS * 32 ** 3
     cin, flop, byt = _work(3, method)
-    return {"metric": f"Mvoxels/sec train-step, the reference's 3D sweep shape: 8 x 32^3 random crops of a {size}^3 volume, method {method} (host loop included)",
-            "value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
+    return {"metric": f"Mvoxels/sec train-step, the reference's 3D sweep shape: 8 x 32^3 random crops of a {size}^3 volume, method {method} ({how})",
+            "value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16x2-split products (weight-gradient operands split on read from fp32 images), f32 accumulate" if args.precision == "split" else _DT[args.precision]),
             "data": "synthetic",

@@ -316,7 +316,31 @@ typedef struct nic_adam_tensor {
                                  gradient bucket of an atomically accumulating step is clean for the next step without a fill kernel; 0 otherwise */
 } nic_adam_tensor;
 #define NIC_ADAM_ZERO_GRAD 1
+#define NIC_ADAM_SCHED_COL1 2 /* nic_adam_multi_dev: this tensor takes its step size from column 1 of the schedule (the decoder group), else column 0 */
 int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
+
+/* ---- hipGraph-captured training loops (no reference counterpart: the reference's loop is host Python, image_compression.py:215-303).
+ *      The reference's own launchers run 320 000 steps of 8 x 32^3 samples: the GPU needs ~0.1 ms per step, the host loop twice that.
+ *      With the step number in DEVICE memory one captured sequence [nic_sampler_step_begin -> nic_fused_forward_backward_img_dev ->
+ *      nic_adam_multi_dev] serves every step and is replayed without the host touching a single argument:
+ *        counters   int64 [2] device: [0] = next step to run, [1] = the step in flight (what the other two entry points read through
+ *                   `step_dev` = counters + 1)
+ *        nic_sampler_step_begin  t = counters[0]; counters[1] = t; counters[0] = t + 1; loss_hist[t - 1] = *loss_slot (the loss the previous
+ *                   step's reduction wrote; either pointer may be null); origins of step t as nic_sampler_draw_origins(seed, t, ..)
+ *        nic_fused_forward_backward_img_dev  nic_fused_forward_backward_img with noise offset desc->noise_offset + *step_dev (in-kernel noise
+ *                   or none; kernels: 2D NIC_FLAG_SPLIT_BF16 with 3 layers, or NIC_FLAG_BF16 - otherwise NIC_E_UNSUPPORTED)
+ *        nic_adam_multi_dev  nic_adam_multi with the per-step scalars read from row min(*step_dev, sched_rows - 1) of `sched`, a device
+ *                   table [sched_rows][4] of floats the caller fills once: {lr_0 / bias_correction1, lr_1 / bias_correction1,
+ *                   sqrt(bias_correction2), 0} for Adam step row + 1 (formed in double and cast once, like nic_adam_multi does per call);
+ *                   nic_adam_tensor.step / .lr are ignored, NIC_ADAM_SCHED_COL1 selects the column. */
+int nic_sampler_step_begin(uint64_t seed, int64_t *counters, int num_crops, int dim, int32_t range, int32_t *origins,
+                           const float *loss_slot, float *loss_hist, int64_t hist_len, void *stream);
+int nic_fused_forward_backward_img_dev(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,
+                                       const nic_mlp *mlp, const nic_target_image *image, float *loss, float *g0_grad, float *g1_grad,
+                                       const nic_mlp_grads *grads, const int64_t *step_dev, void *workspace, size_t workspace_bytes,
+                                       void *stream);
+int nic_adam_multi_dev(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, const float *sched,
+                       int64_t sched_rows, const int64_t *step_dev, void *stream);
 
 /* ---- multi-GPU, stripe-sharded grids (no reference counterpart - the reference is single-device): the per-step exchange buffer
  *      [small | boundary rows of G0 | boundary rows of G1].  `small` = the head of the flat gradient bucket (loss + decoder gradients,

@@ -54,6 +54,7 @@ class NicMlpGrads(ctypes.Structure):
 
 NIC_ADAM_MAX_TENSORS = 32
 NIC_ADAM_ZERO_GRAD = 1
+NIC_ADAM_SCHED_COL1 = 2
 
 
 class NicAdamTensor(ctypes.Structure):
@@ -113,6 +114,9 @@ SIGNATURES = {
     "nic_adam_step": (_I, [_P, _P, _P, _P, _L, _DBL, _DBL, _DBL, _DBL, _L, _F, _F, _P]),
     "nic_gather_corners": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P]),
     "nic_adam_multi": (_I, [ctypes.POINTER(NicAdamTensor), _I, _DBL, _DBL, _DBL, _P]),
+    "nic_sampler_step_begin": (_I, [ctypes.c_uint64, _P, _I, _I, ctypes.c_int32, _P, _P, _P, _L, _P]),
+    "nic_fused_forward_backward_img_dev": (_I, [_D, _P, _P, _P, _M, ctypes.POINTER(NicTargetImage), _P, _P, _P, _G, _P, _P, _SZ, _P]),
+    "nic_adam_multi_dev": (_I, [ctypes.POINTER(NicAdamTensor), _I, _DBL, _DBL, _DBL, _P, _L, _P, _P]),
     "nic_sampler_lod_host": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I]),
     "nic_sampler_origins_host": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "nic_sampler_draw_origins": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, _P, _P]),

@@ -361,7 +361,7 @@ FusedParams zero_params() {
 
 int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp, const float* noise,
                 const float* target, const float* dy, float* y, float* loss, float* g0_grad, float* g1_grad, const nic_mlp_grads* grads,
-                void* workspace, size_t workspace_bytes, void* stream, const nic_target_image* img = nullptr) {
+                void* workspace, size_t workspace_bytes, void* stream, const nic_target_image* img = nullptr, const int64_t* step_dev = nullptr) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
     if (mlp && depth_unsupported(mlp)) return NIC_E_UNSUPPORTED;      // the fused kernels exist for 3 and 5 Linear layers
@@ -407,6 +407,8 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     }
     p.grid_kind = grid_kind_of(d);
     if (p.grid_kind != 0 && !(mlpn || t16 || q16)) return NIC_E_UNSUPPORTED;
+    if (step_dev != nullptr && !(t16 || q16)) return NIC_E_UNSUPPORTED;                // the device-side step: the two-waves-per-SIMD kernels
+    p.step_dev = step_dev;
     p.partials = (float*)workspace;
     const int wpw = (t16 || q16) ? 8 : 4;                     // waves per workgroup = work units per workgroup round
     static const bool two_seg = []() { const char* e = getenv("NIC_TWO_SEG"); return !(e && e[0] == '0'); }();   // NIC_TWO_SEG=0: one segment (A/B timing)
@@ -550,6 +552,15 @@ int nic_fused_forward_backward_img(const nic_path_desc* d, const float* g0, cons
     if (!image || !loss) return NIC_E_NULL;
     return fused_train(d, g0, g1, origins, mlp, noise, nullptr, nullptr, y, loss, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream,
                        image);
+}
+
+int nic_fused_forward_backward_img_dev(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,
+                                       const nic_target_image* image, float* loss, float* g0_grad, float* g1_grad, const nic_mlp_grads* grads,
+                                       const int64_t* step_dev, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!image || !loss || !step_dev) return NIC_E_NULL;
+    if (d && d->noise_mode == NIC_NOISE_TENSOR) return NIC_E_ARG;                      // a captured step draws its noise in the kernel (or none)
+    return fused_train(d, g0, g1, origins, mlp, nullptr, nullptr, nullptr, nullptr, loss, g0_grad, g1_grad, grads, workspace, workspace_bytes, stream,
+                       image, step_dev);
 }
 
 int nic_fused_backward_dy(const nic_path_desc* d, const float* g0, const float* g1, const int32_t* origins, const nic_mlp* mlp,

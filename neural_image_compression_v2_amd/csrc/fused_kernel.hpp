@@ -109,7 +109,20 @@ struct FusedParams {
     int64_t seg_split;     // macro-tiles [0, seg_split) run in 2^rg0_log2 groups of rounds (fused_train16: whole units), the rest in 2^rg_log2 groups; 0 = one segment
     int rg0_log2;
     float grad_scale;      // 2 * loss_scale
+    // hipGraph-captured training loops (nic_fused_forward_backward_img_dev): the step number lives in DEVICE memory and is added to the
+    // noise offset at kernel start, so one captured launch serves every step (fused_train16 / fused_q16 kernels; null everywhere else)
+    const int64_t* step_dev;
 };
+// the launch's noise source with the device-side step added to its offset (uniform: scalar registers)
+__device__ __forceinline__ NoiseSrc noise_with_step(const NoiseSrc& base, const int64_t* step_dev) {
+    NoiseSrc ns = base;
+    if (step_dev != nullptr) {
+        const uint64_t o = (((uint64_t)ns.off_hi << 32) | ns.off_lo) + (uint64_t)*step_dev;
+        ns.off_lo = (uint32_t)o;
+        ns.off_hi = (uint32_t)(o >> 32);
+    }
+    return ns;
+}
 
 // Prologue staging: thread `tid` of NT first ISSUES all of its global loads (elements tid, tid + NT, ...), then converts and stores:
 // one memory round trip for the whole image instead of one per element (the element-at-a-time loops made 20 - 40 dependent round

@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     const int to = T4 >> 1, tk = T4 & 1;
     lds_bf* const img0 = sm + S::OFF_IMG;
     auto barrier = [&]() { wg_lds_barrier(); };
+    const NoiseSrc nsrc = noise_with_step(p.noise, p.step_dev);
 
 #ifdef NIC_STAMPS
     // phases: 0 encode + noise | 1 forward layers | 2 dW_out, dA_last | 3 + 2 j: phase j up to its barrier, 4 + 2 j: its barrier wait + owned dW
@@ -745,7 +746,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 // ---------- input slots
                 float xs[NS];
                 encode_q<Q>(p, q, g, xs, kf, raw);
-                add_noise_q<Q>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+                add_noise_q<Q>(nsrc, (uint64_t)(p.d.sample_base + n), n, g, xs);
                 STAMP(0);
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));                       // 64-column weight images: row n16, columns 8 g ..

@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
     uint32_t bar_target = 0u;
     for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
     __syncthreads();
+    const NoiseSrc nsrc = noise_with_step(p.noise, p.step_dev);
 
     // ---------------- launch-lifetime accumulators: the weight-gradient tiles this wave owns
     f32x16 accW2 = f32x16(0.f);          // dW2 tile (wave & 3), samples of waves 4 (wave >> 2) ..
@@ -574,7 +575,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     EncCtx cx;
                     encode16<L>(p, q, g, xs, cx, raw);
                     kx1 = cx.kx; ky1 = cx.ky;
-                    add_noise16<L>(p.noise, (uint64_t)(p.d.sample_base + n), n, g, xs);
+                    add_noise16<L>(nsrc, (uint64_t)(p.d.sample_base + n), n, g, xs);
                 }
                 STAMP(0);    // coordinates, blend, PE, noise
                 T16_PRIO(1);

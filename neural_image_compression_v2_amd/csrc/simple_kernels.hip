@@ -346,6 +346,12 @@ struct AdamTable {
     AdamEntry e[NIC_ADAM_MAX_TENSORS];
     int count;
     float b2, omb1, omb2, eps;
+    // hipGraph-captured loops (nic_adam_multi_dev): row *step_dev of a device table [rows][4] = {step_size of column 0, step_size of column 1,
+    // sqrt(bias_correction2), -} replaces the per-launch scalars of entry k (column sched_col[k])
+    const float* sched;
+    const int64_t* step_dev;
+    int64_t sched_rows;
+    unsigned char sched_col[NIC_ADAM_MAX_TENSORS];
 };
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamTable& t, float step_size, float bc2_sqrt,
                                          float lo, float hi) {
@@ -360,7 +366,13 @@ constexpr int kAdamChunk = 4096;
 __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
     int k = 0;
     while (k + 1 < t.count && (int)blockIdx.x >= t.e[k + 1].first_block) ++k;
-    const AdamEntry e = t.e[k];
+    AdamEntry e = t.e[k];
+    if (t.sched != nullptr) {
+        int64_t row = *t.step_dev;
+        row = row < 0 ? 0 : (row >= t.sched_rows ? t.sched_rows - 1 : row);
+        e.step_size = t.sched[4 * row + t.sched_col[k]];
+        e.bc2_sqrt = t.sched[4 * row + 2];
+    }
     const int64_t base = (int64_t)((int)blockIdx.x - e.first_block) * kAdamChunk;
     const int64_t left = e.n - base;
     const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
@@ -403,6 +415,23 @@ __global__ void draw_origins_kernel(uint64_t seed, uint64_t step, int num_crops,
     if (i >= num_crops) return;
     const nic::U4 b = nic::sampler_block(seed, step, (uint32_t)i);
     for (int a = 0; a < dim; ++a) out[i * dim + a] = nic::sampler_origin(b, a, range);
+}
+// Head of a hipGraph-captured training step: takes the step number t from a device counter, publishes it for the kernels that follow
+// (counters[1]; the fused step adds it to its noise offset, the optimiser indexes its schedule with it), advances the counter, files the
+// previous step's loss (the reduction of step t - 1 wrote `loss_slot`) and draws the crop origins of step t.  One block.
+__global__ void step_begin_kernel(uint64_t seed, int64_t* counters, int num_crops, int dim, uint32_t range, int32_t* out, const float* loss_slot,
+                                  float* loss_hist, int64_t hist_len) {
+    const int64_t t = counters[0];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[1] = t;
+        counters[0] = t + 1;
+        if (loss_hist != nullptr && loss_slot != nullptr && t >= 1 && t - 1 < hist_len) loss_hist[t - 1] = *loss_slot;
+    }
+    for (int i = threadIdx.x; i < num_crops; i += blockDim.x) {
+        const nic::U4 b = nic::sampler_block(seed, (uint64_t)t, (uint32_t)i);
+        for (int a = 0; a < dim; ++a) out[i * dim + a] = nic::sampler_origin(b, a, range);
+    }
 }
 // planar uint8 [3][n] -> interleaved R | G << 8 | B << 16 (one dword per sample: the fused kernels fetch a target with ONE load)
 __global__ void __launch_bounds__(256) rgbx_interleave_kernel(const uint8_t* src, int64_t n, uint32_t* dst) {
@@ -712,7 +741,31 @@ int nic_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return (int)hipGetLastError();
 }
 
+static int adam_multi_impl(const nic_adam_tensor* tensors, int count, double beta1, double beta2, double eps, const float* sched, int64_t sched_rows,
+                           const int64_t* step_dev, void* stream);
+
 int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, double beta2, double eps, void* stream) {
+    return adam_multi_impl(tensors, count, beta1, beta2, eps, nullptr, 0, nullptr, stream);
+}
+
+int nic_adam_multi_dev(const nic_adam_tensor* tensors, int count, double beta1, double beta2, double eps, const float* sched, int64_t sched_rows,
+                       const int64_t* step_dev, void* stream) {
+    if (!sched || !step_dev) return NIC_E_NULL;
+    if (sched_rows < 1) return NIC_E_ARG;
+    return adam_multi_impl(tensors, count, beta1, beta2, eps, sched, sched_rows, step_dev, stream);
+}
+
+int nic_sampler_step_begin(uint64_t seed, int64_t* counters, int num_crops, int dim, int32_t range, int32_t* origins, const float* loss_slot,
+                           float* loss_hist, int64_t hist_len, void* stream) {
+    if (!counters || !origins) return NIC_E_NULL;
+    if (num_crops < 1 || dim < 2 || dim > 3 || range < 1 || hist_len < 0) return NIC_E_ARG;
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seed, counters, num_crops, dim, (uint32_t)range, origins, loss_slot,
+                       loss_hist, hist_len);
+    return (int)hipGetLastError();
+}
+
+static int adam_multi_impl(const nic_adam_tensor* tensors, int count, double beta1, double beta2, double eps, const float* sched, int64_t sched_rows,
+                           const int64_t* step_dev, void* stream) {
     if (count == 0) return NIC_OK;
     if (!tensors) return NIC_E_NULL;
     if (count < 0 || count > NIC_ADAM_MAX_TENSORS) return NIC_E_ARG;
@@ -724,7 +777,7 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, doub
         const nic_adam_tensor& a = tensors[i];
         if (a.n == 0) continue;
         if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) return NIC_E_NULL;
-        if (a.n < 0 || a.step < 1) return NIC_E_ARG;
+        if (a.n < 0 || (a.step < 1 && !sched)) return NIC_E_ARG;
         const double bc1 = 1.0 - pow(beta1, (double)a.step);
         const double bc2 = 1.0 - pow(beta2, (double)a.step);
         AdamEntry& e = t.e[nt++];
@@ -733,8 +786,9 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, doub
         e.bc2_sqrt = (float)sqrt(bc2);
         e.lo = a.clamp_lo; e.hi = a.clamp_hi;
         e.p16 = (uint16_t*)a.param16; e.p16_kind = a.param16_kind;
-        if (a.flags & ~NIC_ADAM_ZERO_GRAD) return NIC_E_ARG;
+        if (a.flags & ~(NIC_ADAM_ZERO_GRAD | NIC_ADAM_SCHED_COL1)) return NIC_E_ARG;
         e.zero_g = (a.flags & NIC_ADAM_ZERO_GRAD) ? 1 : 0;
+        t.sched_col[nt - 1] = (a.flags & NIC_ADAM_SCHED_COL1) ? 1 : 0;
         if (e.p16 != nullptr && e.p16_kind != 1 && e.p16_kind != 2) return NIC_E_ARG;
         e.first_block = (int)blocks;
         blocks += (a.n + kAdamChunk - 1) / kAdamChunk;
@@ -742,6 +796,7 @@ int nic_adam_multi(const nic_adam_tensor* tensors, int count, double beta1, doub
     }
     if (nt == 0) return NIC_OK;
     t.count = nt;
+    t.sched = sched; t.step_dev = step_dev; t.sched_rows = sched_rows;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }

@@ -546,6 +546,20 @@ class StepPlan:
                 "nic_fused_forward_backward_img")
         return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)
 
+    def launch_dev(self, origins_dev: torch.Tensor, step_dev_ptr: int, loss_slot: torch.Tensor, ws: torch.Tensor, noise_mode: int, noise_seed: int,
+                   noise_base: int = 0) -> None:
+        """the step of a hipGraph-captured loop (``nic_fused_forward_backward_img_dev``): origins from a device buffer, the step number from
+        device memory (added to ``noise_base``), the loss into ``loss_slot``.  Touches no host state and allocates nothing: capture-safe; the
+        grid-gradient part of the bucket must be clean (``optim.FusedAdam`` zeroes it in its own launch, NIC_ADAM_ZERO_GRAD)."""
+        d = self.d
+        d.noise_mode = int(noise_mode)
+        d.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
+        d.noise_offset = int(noise_base) & 0xFFFFFFFFFFFFFFFF
+        _lib.check(self.lib.nic_fused_forward_backward_img_dev(
+            ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(origins_dev), ctypes.byref(self.m), ctypes.byref(self.timg),
+            _lib.ptr(loss_slot), _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), ctypes.c_void_p(step_dev_ptr), _lib.ptr(ws), ws.numel(),
+            _lib.stream_ptr(self.dev)), "nic_fused_forward_backward_img_dev")
+
 
 # ------------------------------------------------------------------------------------------------------
 # autograd

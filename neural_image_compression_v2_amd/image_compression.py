@@ -10,6 +10,7 @@ backward; every op a HIP kernel of this package) and the fused single-launch ste
 from __future__ import annotations
 
 import math
+import ctypes
 import os
 import random
 import time
@@ -357,6 +358,108 @@ class ImageCompression:
             self.step_count += 1
             if log_every and (epoch + 1) % log_every == 0:
                 print(f"Epoch [{epoch + 1}/{c.NUM_EPOCHS}], Loss: {loss.item():.4f}", flush=True)
+        return fp
+
+    def train_models_graph(self, fp, steps_per_graph: int = 8, log_every: int = 0, noise_seed: int = 7, time_replays: bool = False):
+        """``train_models`` with the host out of the loop: the noisy, unfrozen part of the schedule (epochs below 0.95 NUM_EPOCHS,
+        image_compression.py:227-254) runs as replays of ONE captured hipGraph of ``steps_per_graph`` steps - [draw the crop origins from the
+        device step counter | fused forward + backward with the step number added to the noise offset | Adam + clamp with the step's learning
+        rates from a device table filled once with the cosine schedule] - no argument is rewritten, no upload, no Python per step.  The
+        reference's own launchers (320 000 steps of 8 x 32^3 samples) are host-bound everywhere else: their step needs ~0.1 ms of GPU.
+        Same arithmetic as ``train_models`` with TF_DEVICE_SAMPLER (same origins, noise, learning rates: the losses agree to the order of the
+        atomic sums).  Needs TF_DEVICE_SAMPLER (origins on the device) and TF_NO_MIP (the LOD fixes the launch geometry); the tail from
+        0.95 NUM_EPOCHS on runs through ``train_step`` like ``train_models``."""
+        c = self.cfg
+        if getattr(self, "_sampler", None) is None:
+            raise ValueError("train_models_graph draws its crop origins on the device: TF_DEVICE_SAMPLER=True and set_images([uint8 codes])")
+        if c.MAX_MIP_LEVEL != 0:
+            raise NotImplementedError("the LOD decides the launch geometry on the host: captured loops need TF_NO_MIP (the reference's default)")
+        if not isinstance(self.optimizer, FusedAdam):
+            raise TypeError("train_models_graph captures optim.FusedAdam's launch")
+        D, N, e0 = c.FP_DIMENSION, c.NUM_EPOCHS, self.step_count
+        e_end = min(N, int(math.ceil(N * 0.95)))                       # epochs e < 0.95 N: noise on, grids trainable
+        n = max(0, e_end - e0)
+        dev = self.device
+        if n > 0:
+            lod, fl = 0, self.feature_pyramid_mip_levels_dict[0]
+            geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=noise_seed, noise_offset=0,
+                                 split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16)
+            lin = self.decoder.linear_params()
+            target = self._targets[lod]
+            plans = self.__dict__.setdefault("_plans", {})
+            plan = plans.get((fl, lod))
+            if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
+                plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
+            for t in fp:
+                t.grad = None
+            fp[2 * fl].grad, fp[2 * fl + 1].grad = plan.gg0, plan.gg1
+            for p_, g_ in zip(lin, plan.gm):
+                p_.grad = g_
+            pairs = [(fp[2 * fl], plan.gg0), (fp[2 * fl + 1], plan.gg1)] + list(zip(lin, plan.gm))
+            adam = self.optimizer.dev_table(pairs, e0, self.scheduler.peek(n))
+            if not (plan.gg0.data_ptr() in adam.zeroed and plan.gg1.data_ptr() in adam.zeroed):
+                raise RuntimeError("the captured step relies on the optimiser zeroing the grid-gradient bucket (FusedAdam.zero_grad_in_step)")
+            plan.flat.zero_()
+            counters = torch.tensor([e0, e0], dtype=torch.int64, device=dev)
+            step_ptr = counters.data_ptr() + 8
+            hist = torch.zeros(e_end, dtype=torch.float32, device=dev)
+            loss_slot = torch.zeros(1, dtype=torch.float32, device=dev)
+            lib = _lib.load()
+            ws = torch.empty(int(lib.nic_workspace_bytes(ctypes.byref(plan.d))), dtype=torch.uint8, device=dev)
+            re_crop = max(1, c.CROP_SIZE // pow(2, lod))
+            rng = int(target.spatial[0]) - re_crop + 1
+            org = torch.zeros(c.NUM_CROPS * D, dtype=torch.int32, device=dev)
+            seed = self._sampler.seed
+
+            def one_step():
+                _lib.check(lib.nic_sampler_step_begin(seed, _lib.ptr(counters), c.NUM_CROPS, D, rng, _lib.ptr(org), _lib.ptr(loss_slot), _lib.ptr(hist),
+                                                      hist.numel(), _lib.stream_ptr(dev)), "nic_sampler_step_begin")
+                plan.launch_dev(org, step_ptr, loss_slot, ws, _lib.NIC_NOISE_KERNEL, noise_seed)
+                adam.launch(step_ptr)
+
+            with torch.cuda.device(dev):
+                one_step()                                              # the first step uncaptured: argument errors surface here, not inside a capture
+                done = 1
+                K = max(1, int(steps_per_graph))
+                if (n - done) >= K:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for _ in range(K):
+                            one_step()
+                    if time_replays:                                    # benchmarks: wall time of the replay loop alone (two host syncs)
+                        torch.cuda.synchronize(dev)
+                        t0, d0 = time.perf_counter(), done
+                    while n - done >= K:
+                        graph.replay()
+                        done += K
+                        if log_every and done % log_every < K:
+                            print(f"Epoch [{e0 + done}/{N}]", flush=True)
+                    if time_replays:
+                        torch.cuda.synchronize(dev)
+                        self.graph_timing = {"steps": done - d0, "seconds": time.perf_counter() - t0, "steps_per_graph": K}
+                while done < n:                                         # the remainder, same launches without a capture
+                    one_step()
+                    done += 1
+                hist[e_end - 1:e_end].copy_(loss_slot)                  # the last step's loss has no successor to file it
+            self._graph_keep = (counters, hist, loss_slot, ws, org, adam)   # alive until the stream has drained
+            adam.commit(n)
+            self.scheduler.advance(n)
+            plan.clean = True
+            plan.steps += n
+            self.loss_history.extend(hist[e] for e in range(e0, e_end))
+            self.step_count += n
+            for _ in range(n):
+                self._uniform()                                         # the loop's uniform-LOD accumulator advances per step (unused at MAX_MIP_LEVEL 0)
+        # the tail: no noise at 0.95 N exactly (Q4), then frozen grids / quantised copies (image_compression.py:227-231)
+        frozen = False
+        for epoch in range(self.step_count, N):
+            if epoch > N * 0.95 and not frozen:
+                fp_freeze(fp)
+                fp = fp_all_quantize(fp, c.FP_BITS)
+                frozen = True
+            loss = self.train_step(fp, epoch, True, noise_seed)
+            self.loss_history.append(loss)
+            self.step_count += 1
         return fp
 
     # ------------------------------------------------------------------ decode (image_compression.py:307-346)

@@ -118,6 +118,60 @@ class FusedAdam(torch.optim.Optimizer):
         self._remember(batches, device)
         return loss
 
+    # ---- hipGraph-captured loops: the launch reads its per-step scalars from a device table (nic_adam_multi_dev)
+    def dev_table(self, pairs, first_step_row: int, lrs_per_step) -> "DevAdam":
+        """``pairs``: [(parameter, its gradient buffer)] - every parameter of the captured step.  ``lrs_per_step``: per future step a list of
+        per-group learning rates (``CosineAnnealing.peek``).  Row ``first_step_row + k`` of the schedule holds the scalars of the k-th step
+        from now: lr / bias_correction1 per group (formed in double, cast once - what nic_adam_multi does per call) and
+        sqrt(bias_correction2).  All parameters must share one step count (they do when every step updates all of them) and one
+        (betas, eps); at most two parameter groups (the reference's: grids, decoder)."""
+        import math
+        if len(self.param_groups) > 2:
+            raise NotImplementedError("two parameter groups (grids, decoder), like the reference's optimiser (image_compression.py:361-364)")
+        keys = {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups}
+        if len(keys) != 1:
+            raise NotImplementedError("one (betas, eps) for all groups")
+        (b1, b2, eps), = keys
+        gidx = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        entries, steps, zeroed = [], set(), set()
+        for p, g in pairs:
+            if id(p) not in gidx:
+                raise ValueError("a captured parameter is not registered in this optimiser")
+            _lib.require_cuda_f32(p, "parameter")
+            if not (p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32):
+                raise RuntimeError("captured parameters and gradient buffers are contiguous fp32")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.add(int(st["step"].item()))
+            lo, hi = self._clamp.get(id(p), (1.0, -1.0))
+            mir = self._mirror.get(id(p))
+            flags = (_lib.NIC_ADAM_ZERO_GRAD if id(p) in self._zero else 0) | (_lib.NIC_ADAM_SCHED_COL1 if gidx[id(p)] == 1 else 0)
+            if id(p) in self._zero:
+                zeroed.add(g.data_ptr())
+            entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), 0, 0.0, lo, hi,
+                                              0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), flags))
+        if len(steps) != 1:
+            raise RuntimeError("captured parameters must share one Adam step count")
+        if len(entries) > _lib.NIC_ADAM_MAX_TENSORS:
+            raise NotImplementedError(f"at most {_lib.NIC_ADAM_MAX_TENSORS} tensors per captured optimiser launch")
+        s0 = steps.pop()
+        n = len(lrs_per_step)
+        import numpy as np
+        rows = np.zeros((first_step_row + n, 4), dtype=np.float32)
+        for k, lrs in enumerate(lrs_per_step):
+            step = s0 + k + 1
+            bc1, bc2 = 1.0 - math.pow(b1, float(step)), 1.0 - math.pow(b2, float(step))
+            rows[first_step_row + k, 0] = np.float32(float(lrs[0]) / bc1)
+            rows[first_step_row + k, 1] = np.float32(float(lrs[-1]) / bc1)
+            rows[first_step_row + k, 2] = np.float32(math.sqrt(bc2))
+        dev = pairs[0][0].device
+        self._cache = None
+        return DevAdam(self, (_lib.NicAdamTensor * len(entries))(*entries), len(entries), (b1, b2, eps), torch.from_numpy(rows).to(dev), [p for p, _ in pairs],
+                       frozenset(zeroed), dev)
+
     # ---- the steady state of a training loop: the same parameters, the same gradient / state buffers (the fused step writes its gradients
     # into one reused bucket), one launch.  The table of the previous step is reused when every pointer in it is still current; only
     # the step counts and learning rates are rewritten (the full path above costs ~60 us of Python per step).
@@ -172,6 +226,25 @@ class FusedAdam(torch.optim.Optimizer):
         return True
 
 
+class DevAdam:
+    """the captured optimiser launch of ``FusedAdam.dev_table``: ``launch(step_dev_ptr)`` inside the capture, ``commit(n)`` once the replays
+    are done (host-side step counts of the ``state_dict``)"""
+
+    def __init__(self, opt, arr, count, key, sched, params, zeroed, device):
+        self.opt, self.arr, self.count, self.key, self.sched, self.params, self.zeroed, self.device = opt, arr, count, key, sched, params, zeroed, device
+
+    def launch(self, step_dev_ptr: int) -> None:
+        b1, b2, eps = self.key
+        _lib.check(_lib.load().nic_adam_multi_dev(self.arr, self.count, b1, b2, eps, _lib.ptr(self.sched), int(self.sched.shape[0]),
+                                                  ctypes.c_void_p(step_dev_ptr), _lib.stream_ptr(self.device)), "nic_adam_multi_dev")
+
+    def commit(self, n_steps: int) -> None:
+        for p in self.params:
+            self.opt.state[p]["step"] += n_steps
+        self.opt._zeroed = self.zeroed
+        self.opt._cache = None
+
+
 class CosineAnnealing:
     """``torch.optim.lr_scheduler.CosineAnnealingLR`` for the training loop, without its per-step Python machinery (70 us of a 230 us
     host loop): the same chainable recurrence evaluated in the same order in double precision, so the learning rates are bit-identical to
@@ -201,6 +274,28 @@ class CosineAnnealing:
             f = (1 + math.cos(math.pi * t / T)) / (1 + math.cos(math.pi * (t - 1) / T))
             for g in self.optimizer.param_groups:
                 g["lr"] = f * (g["lr"] - self.eta_min) + self.eta_min
+
+    def peek(self, n: int):
+        """the learning rates of the next ``n`` optimiser steps (entry 0 = the current ones), per group, without stepping: the very recurrence of
+        ``step`` on local copies - bit-identical to stepping"""
+        import math
+        lrs = [float(g["lr"]) for g in self.optimizer.param_groups]
+        t, T = self.last_epoch, self.T_max
+        out = []
+        for _ in range(n):
+            out.append(list(lrs))
+            t += 1
+            if (t - 1 - T) % (2 * T) == 0:
+                lrs = [lr + (base_lr - self.eta_min) * (1 - math.cos(math.pi / T)) / 2 for lr, base_lr in zip(lrs, self.base_lrs)]
+            else:
+                f = (1 + math.cos(math.pi * t / T)) / (1 + math.cos(math.pi * (t - 1) / T))
+                lrs = [f * (lr - self.eta_min) + self.eta_min for lr in lrs]
+        return out
+
+    def advance(self, n: int) -> None:
+        """``n`` calls of ``step``"""
+        for _ in range(n):
+            self.step()
 
     def state_dict(self):
         return {"T_max": self.T_max, "eta_min": self.eta_min, "base_lrs": list(self.base_lrs), "last_epoch": self.last_epoch}

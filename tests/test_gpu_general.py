@@ -296,3 +296,92 @@ def test_multilevel_field_trains_and_decodes(dev):
     assert relmax(rec, O.mlp_forward(xr, mlp_fin).reshape(S[0], S[1], 3)) < 2e-5
     mse = float(((rec - tgt) ** 2).mean())
     assert mse < 0.3 * float(((0.5 - tgt) ** 2).mean())
+
+
+# ------------------------------------------------------------------------------------------------------
+# hipGraph-captured training loop (ImageCompression.train_models_graph; nic_sampler_step_begin, nic_fused_forward_backward_img_dev, nic_adam_multi_dev)
+# ------------------------------------------------------------------------------------------------------
+GRAPH_CASES = [
+    dict(IMAGE_SIZE=512, NUM_CROPS=4),                                                             # 2D, split-bf16 products: fused_train16
+    dict(IMAGE_SIZE=512, NUM_CROPS=4, TF_PLAIN_BF16=1),                                            # 2D, plain bf16: fused_q16
+    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=4, CROP_MIP_LEVEL=5, NUM_CROPS=8),   # the reference's sweep shape, method 4 (plain bf16 by default)
+    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, CROP_MIP_LEVEL=5, NUM_CROPS=8, MLP_NUM_DTYPE=16),   # method 3, float16 grid storage
+    dict(IMAGE_SIZE=512, NUM_CROPS=2, TF_PLAIN_BF16=1, DECODER_LINEAR_LAYERS=5, TF_GRID_BF16=True),   # the north star's decoder and storage
+]
+
+
+@pytest.mark.parametrize("flags", GRAPH_CASES, ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()))
+def test_graph_captured_loop_matches_the_host_loop(dev, flags):
+    """the same fit twice - train_models (host loop, device sampler) and train_models_graph (captured replays: origins, noise offset, Adam
+    step and cosine learning rate all taken from device memory): same origins, same noise, same learning rates, so the loss of every step,
+    the final grids, decoder and optimiser state agree to the order of the atomic sums; the tail after 0.95 NUM_EPOCHS runs in both"""
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    res = {}
+    for mode in ("host", "graph"):
+        cfg = Settings(NUM_EPOCHS=50, TF_NO_MIP=True, TF_DEVICE_SAMPLER=True, SAMPLER_SEED=11, **flags)
+        D, S = cfg.FP_DIMENSION, cfg.IMAGE_SIZE
+        den = 255.0 if D == 2 else 256.0
+        ic = ImageCompression(cfg, dev, seed=0)
+        ic.set_images([torch.round(_image(S, D) * (den - 1)).to(torch.uint8)], den=den)
+        if mode == "host":
+            fp = ic.train_models(ic.feature_pyramid)
+        else:
+            fp = ic.train_models_graph(ic.feature_pyramid, steps_per_graph=8)
+        torch.cuda.synchronize()
+        assert ic.step_count == 50 and len(ic.loss_history) == 50
+        st = ic.optimizer.state
+        res[mode] = dict(loss=torch.stack([l.reshape(()) for l in ic.loss_history]).cpu(), fp=[g.detach().cpu() for g in ic.feature_pyramid],
+                         dec=[p.detach().cpu() for p in ic.decoder.linear_params()], lr=[g["lr"] for g in ic.optimizer.param_groups],
+                         steps=[int(st[p]["step"].item()) for p in ic.feature_pyramid], m=[st[p]["exp_avg"].cpu() for p in ic.feature_pyramid],
+                         psnr=float(ic.psnr(fp)))
+    h, g = res["host"], res["graph"]
+    assert h["lr"] == g["lr"] and h["steps"] == g["steps"]                  # bit-identical schedule, same step counts (grids stop at the freeze)
+    assert bool(torch.isfinite(g["loss"]).all()) and float(g["loss"][-5:].mean()) < float(g["loss"][:5].mean())
+    rel = float(((h["loss"] - g["loss"]).abs() / h["loss"]).max())
+    assert rel < 2e-3, rel                                                  # atomic summation order only (measured ~1e-5; bf16 modes amplify it)
+    for a, b in zip(h["fp"] + h["dec"] + h["m"], g["fp"] + g["dec"] + g["m"]):
+        assert relmax(b, a) < 5e-3, relmax(b, a)
+    assert abs(h["psnr"] - g["psnr"]) < 0.02
+
+
+def test_step_begin_and_adam_dev_entry_points(dev):
+    """nic_sampler_step_begin: counters, loss filing and the origins of nic_sampler_draw_origins; nic_adam_multi_dev against nic_adam_multi
+    step by step (schedule rows = what the host call forms per step: bit-identical parameters)"""
+    from neural_image_compression_v2_amd import _lib
+    from neural_image_compression_v2_amd.optim import CosineAnnealing, FusedAdam
+    from neural_image_compression_v2_amd.sampler import DeviceSampler
+    lib = _lib.load()
+    counters = torch.tensor([5, -1], dtype=torch.int64, device=dev)
+    org = torch.zeros(8 * 3, dtype=torch.int32, device=dev)
+    slot = torch.tensor([0.25], device=dev)
+    hist = torch.zeros(10, device=dev)
+    _lib.check(lib.nic_sampler_step_begin(123, _lib.ptr(counters), 8, 3, 33, _lib.ptr(org), _lib.ptr(slot), _lib.ptr(hist), 10, _lib.stream_ptr(dev)))
+    assert counters.tolist() == [6, 5] and hist.tolist() == [0, 0, 0, 0, 0.25, 0, 0, 0, 0, 0]
+    smp = DeviceSampler(123, dev)
+    assert torch.equal(org.view(8, 3).cpu(), smp.origins_host(5, 8, 3, 33))
+    # Adam: two groups, 12 steps, clamp on the first group
+    torch.manual_seed(0)
+    def make():
+        a = torch.nn.Parameter(torch.rand(5000, device=dev) - 0.5)
+        b = torch.nn.Parameter(torch.randn(64, 73, device=dev))
+        opt = FusedAdam([{"params": [a], "lr": 0.01}, {"params": [b], "lr": 0.005}])
+        opt.set_clamp([a], -0.498, 0.5)
+        return a, b, opt, CosineAnnealing(opt, T_max=20)
+    torch.manual_seed(1); a1, b1, o1, s1 = make()
+    torch.manual_seed(1); a2, b2, o2, s2 = make()
+    ga, gb = torch.zeros_like(a1), torch.zeros_like(b1)
+    a2.grad, b2.grad = ga, gb
+    adam = o2.dev_table([(a2, ga), (b2, gb)], 3, s2.peek(12))
+    ctr = torch.tensor([3], dtype=torch.int64, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for k in range(12):
+        ga.copy_(torch.randn(5000, device=dev, generator=gen)); gb.copy_(torch.randn(64, 73, device=dev, generator=gen))
+        a1.grad, b1.grad = ga.clone(), gb.clone()
+        o1.step(); s1.step()
+        adam.launch(ctr.data_ptr())
+        ctr += 1
+    adam.commit(12); s2.advance(12)
+    assert torch.equal(a1.detach(), a2.detach()) and torch.equal(b1.detach(), b2.detach())
+    assert [g["lr"] for g in o1.param_groups] == [g["lr"] for g in o2.param_groups]
+    assert int(o2.state[a2]["step"].item()) == 12
