@@ -250,6 +250,14 @@ int nic_sampler_draw_origins(uint64_t seed, uint64_t step, int num_crops, int di
  *      mip 0, the only level of the no-mip default, is exact). */
 int nic_rgbx_interleave(const uint8_t *planar, int64_t n, uint32_t *rgbx, void *stream);
 int nic_rgbx_downsample2(const uint32_t *src_rgbx, int s0, int s1, uint32_t *dst_rgbx, void *stream);
+/* ---- the reference's OWN mip filter: transforms.Resize on the PIL image (image_compression.py:434-440) is Pillow's two-pass fixed-point resize
+ *      (src/libImaging/Resample.c; torchvision is a thin wrapper: functional.resize -> Image.resize(size, BILINEAR)).  One pass along `axis` of an RGBX
+ *      image [s0][s1] (axis 1 = the contiguous one; Pillow runs it first, then axis 0): out = clip8((2^21 + sum_t pixel[lo + t] * kk[o][t]) >> 22) per
+ *      channel, taps [lo, lo + count) = bounds[o][0..1], kk int32 [out_size][ksize] in 2^-22 units - precompute_coeffs + normalize_coeffs_8bpc, restated
+ *      on the host by sampler.resize_coeffs.  Every level is resized from the ORIGINAL image, like the reference.  Bit-exact against Pillow
+ *      (tests/test_host_cpu.py pins the coefficients, tests/test_gpu_general.py the images). */
+int nic_rgbx_resample_axis(const uint32_t *src_rgbx, int s0, int s1, int axis, int out_size, const int32_t *bounds, const int32_t *kk, int ksize,
+                           uint32_t *dst_rgbx, void *stream);
 
 /* ---- decode straight from the stored codec (image_compression.py:307-346 after fp_load, fp_def.py:258-263):
  *      the grids are the uint8 tensors fp_savable wrote (models.py:61-64), dequantised in-kernel exactly like load4fp

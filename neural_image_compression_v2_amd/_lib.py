@@ -122,6 +122,7 @@ SIGNATURES = {
     "nic_sampler_draw_origins": (_I, [ctypes.c_uint64, ctypes.c_uint64, _I, _I, ctypes.c_int32, _P, _P]),
     "nic_rgbx_interleave": (_I, [_P, _L, _P, _P]),
     "nic_rgbx_downsample2": (_I, [_P, _I, _I, _P, _P]),
+    "nic_rgbx_resample_axis": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "nic_stripe_pack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
     "nic_stripe_unpack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
 }

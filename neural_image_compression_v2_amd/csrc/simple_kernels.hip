@@ -455,6 +455,31 @@ __global__ void __launch_bounds__(256) rgbx_down2_kernel(const uint32_t* src, in
     }
 }
 
+// One pass of Pillow's two-pass resize (src/libImaging/Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc) on an RGBX image - what
+// torchvision's transforms.Resize runs on the PIL image the reference builds its mip chain from (image_compression.py:434-440): out = clip8((2^21 +
+// sum over the taps of pixel * k) >> 22) per channel with the caller's fixed-point coefficients (sampler.resize_coeffs restates precompute_coeffs +
+// normalize_coeffs_8bpc).  axis 1: along the contiguous axis, dst [s0][out]; axis 0: across rows, dst [out][s1].
+__global__ void __launch_bounds__(256) rgbx_resample_kernel(const uint32_t* src, int s0, int s1, int axis, int out_size, const int32_t* bounds, const int32_t* kk,
+                                                            int ksize, uint32_t* dst) {
+    const int64_t n = axis == 1 ? (int64_t)s0 * out_size : (int64_t)out_size * s1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = axis == 1 ? out_size : s1;
+        const int r = (int)(i / w), c = (int)(i - (int64_t)r * w);
+        const int o = axis == 1 ? c : r;
+        const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
+        const int32_t* k = kk + (int64_t)o * ksize;
+        int ss0 = 1 << 21, ss1 = 1 << 21, ss2 = 1 << 21;
+        for (int t = 0; t < cnt; ++t) {
+            const uint32_t px = axis == 1 ? src[(int64_t)r * s1 + lo + t] : src[(int64_t)(lo + t) * s1 + c];
+            ss0 += (int)(px & 255u) * k[t];
+            ss1 += (int)((px >> 8) & 255u) * k[t];
+            ss2 += (int)((px >> 16) & 255u) * k[t];
+        }
+        auto clip8 = [](int v) { v >>= 22; return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+        dst[i] = clip8(ss0) | (clip8(ss1) << 8) | (clip8(ss2) << 16);
+    }
+}
+
 static inline int blocks_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -727,6 +752,15 @@ int nic_rgbx_downsample2(const uint32_t* src, int s0, int s1, uint32_t* dst, voi
     if (!src || !dst) return NIC_E_NULL;
     if (s0 < 2 || s1 < 2) return NIC_E_ARG;
     hipLaunchKernelGGL(rgbx_down2_kernel, dim3(blocks_for((int64_t)(s0 >> 1) * (s1 >> 1))), dim3(256), 0, (hipStream_t)stream, src, s0, s1, dst);
+    return (int)hipGetLastError();
+}
+
+int nic_rgbx_resample_axis(const uint32_t* src, int s0, int s1, int axis, int out_size, const int32_t* bounds, const int32_t* kk, int ksize, uint32_t* dst,
+                           void* stream) {
+    if (!src || !dst || !bounds || !kk) return NIC_E_NULL;
+    if (s0 < 1 || s1 < 1 || out_size < 1 || ksize < 1 || (axis != 0 && axis != 1)) return NIC_E_ARG;
+    const int64_t n = axis == 1 ? (int64_t)s0 * out_size : (int64_t)out_size * s1;
+    hipLaunchKernelGGL(rgbx_resample_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, s0, s1, axis, out_size, bounds, kk, ksize, dst);
     return (int)hipGetLastError();
 }
 

@@ -192,7 +192,7 @@ class ImageCompression:
             from .sampler import DeviceSampler, build_rgbx_pyramid
             if self.images[0].dtype != torch.uint8:
                 raise ValueError("TF_DEVICE_SAMPLER needs the uint8 codes of the image (set_images([...uint8...]))")
-            self._targets = build_rgbx_pyramid(self.images[0], self.cfg.MAX_MIP_LEVEL + 1, den)
+            self._targets = build_rgbx_pyramid(self.images[0], self.cfg.MAX_MIP_LEVEL + 1, den, self.cfg.TF_MIP_FILTER)
             self._sampler = DeviceSampler(self.cfg.SAMPLER_SEED, self.device, self.cfg.NUM_CROPS)
 
     # ------------------------------------------------------------------ one training iteration

@@ -49,14 +49,82 @@ def rgbx_downsample2(level: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def build_rgbx_pyramid(image_u8: torch.Tensor, levels: int, den: float = 255.0) -> List[fused.TargetImage]:
-    """``levels`` resident target images (LOD 0 .. levels - 1) as :class:`fused.TargetImage` in the RGBX layout"""
-    cur = rgbx_interleave(image_u8)
+def resize_coeffs(in_size: int, out_size: int):
+    """Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` for the BILINEAR filter (src/libImaging/Resample.c) - the arithmetic behind
+    ``transforms.Resize`` on a PIL image (image_compression.py:434-440) - restated operation for operation in double precision: per output index
+    the first tap, the tap count, and the taps' weights as int32 in 2^-22 units.  Returns ``(bounds [out, 2], kk [out, ksize], ksize)`` (numpy)."""
+    import math
+    import numpy as np
+    scale = float(in_size) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale                                       # bilinear: support 1
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        ww = 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def rgbx_resize(level0: torch.Tensor, out0: int, out1: int) -> torch.Tensor:
+    """Pillow's BILINEAR ``Image.resize`` of an RGBX image ``[S0, S1]`` to ``[out0, out1]`` (``transforms.Resize((out0, out1))`` of the reference,
+    image_compression.py:434-440), bit-exact: the pass along the contiguous axis first, then across rows, each rounding to bytes"""
+    if level0.dtype != torch.int32 or level0.dim() != 2 or not level0.is_cuda:
+        raise ValueError("expects a 2D RGBX level on the device")
+    s0, s1 = int(level0.shape[0]), int(level0.shape[1])
+    dev = level0.device
+    lib = _lib.load()
+    cur = level0.contiguous()
+    with torch.cuda.device(dev):
+        for axis, out in ((1, out1), (0, out0)):
+            in_size = s1 if axis == 1 else s0
+            if out == in_size:
+                continue                                              # Pillow skips a pass that does not change the size
+            bounds, kk, ksize = resize_coeffs(in_size, out)
+            b, k = torch.from_numpy(bounds).to(dev), torch.from_numpy(kk).to(dev)
+            dst = torch.empty((s0, out) if axis == 1 else (out, s1), dtype=torch.int32, device=dev)
+            _lib.check(lib.nic_rgbx_resample_axis(_lib.ptr(cur), s0, s1, axis, out, _lib.ptr(b), _lib.ptr(k), ksize, _lib.ptr(dst), _lib.stream_ptr(dev)),
+                       "nic_rgbx_resample_axis")
+            cur = dst
+            s0, s1 = int(cur.shape[0]), int(cur.shape[1])
+    return cur
+
+
+def build_rgbx_pyramid(image_u8: torch.Tensor, levels: int, den: float = 255.0, mip_filter: str = "resize") -> List[fused.TargetImage]:
+    """``levels`` resident target images (LOD 0 .. levels - 1) as :class:`fused.TargetImage` in the RGBX layout.  2D, ``mip_filter``:
+    "resize" (default) = the reference's own chain - every level is ``transforms.Resize(S // 2^i)`` of the ORIGINAL image, i.e. Pillow's BILINEAR
+    resize (image_compression.py:432-440), reproduced bit for bit by :func:`rgbx_resize`; "box" = level k + 1 by a 2 x 2 box filter of level k
+    (round 2's filter).  3D: every LOD reads the full-resolution volume, like the reference (:470-477)."""
+    if mip_filter not in ("resize", "box"):
+        raise ValueError("mip_filter is 'resize' (the reference's) or 'box'")
+    base = rgbx_interleave(image_u8)
+    cur = base
     out = [fused.TargetImage(cur, den, rgbx=True)]
-    for _ in range(1, levels):
-        if cur.dim() == 2:
-            cur = rgbx_downsample2(cur)
-        out.append(fused.TargetImage(cur, den, rgbx=True))           # 3D: every LOD reads the full-resolution volume, like the reference
+    for i in range(1, levels):
+        if base.dim() == 2:
+            cur = rgbx_resize(base, int(base.shape[0]) // 2 ** i, int(base.shape[1]) // 2 ** i) if mip_filter == "resize" else rgbx_downsample2(cur)
+        out.append(fused.TargetImage(cur, den, rgbx=True))
     return out
 
 

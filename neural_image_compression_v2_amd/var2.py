@@ -55,6 +55,8 @@ class Settings:
                                          # from the resident RGBX pyramid instead of the host RNG calls of random_crop_dataset - no host
                                          # round-trip per step; False keeps the reference's RNG streams (random / torch.randint) draw for draw
     SAMPLER_SEED: int = 0
+    TF_MIP_FILTER: str = "resize"       # not in the reference: how TF_DEVICE_SAMPLER builds its RGBX mip levels - "resize" = the reference's own transforms.Resize chain
+                                         # (Pillow's BILINEAR resize of the original image, image_compression.py:432-440, bit-exact), "box" = 2 x 2 box filter level by level
     TF_TRAIN_MODEL: bool = True
     TF_SHOW_RESULT: bool = False
     TF_PRINT_LOG: bool = True

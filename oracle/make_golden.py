@@ -585,6 +585,20 @@ def g11_stored(ref_models, ref_utils, ref_fp):
     save("stored_decode", y=y, y_to_bit=ref_models.quantize_to_bit(y, 8), g0_u8=stored[0], g1_u8=stored[1])
 
 
+def g12_mipchain():
+    """The reference's dataset chain (image_compression.py:432-440): ``transforms.Resize((S // 2^i, S // 2^i))`` + ``ToTensor`` of the PIL image.
+    torchvision is not installed here; its ``Resize`` on a PIL image is ``functional.resize -> F_pil.resize -> img.resize(size[::-1], BILINEAR)``,
+    so the fixture is produced by that Pillow call on a 128 x 128 crop of the reference's own sample image: the crop's codes and Pillow's levels
+    64 .. 1 (each resized from the crop, like the reference resizes every level from the original)."""
+    from PIL import Image
+    img = Image.open("/root/reference/Projects/data/sancho_512.png").convert("RGB").crop((192, 160, 320, 288))
+    arrays = {"image": np.asarray(img)}
+    for i in range(1, 8):
+        s = 128 // 2 ** i
+        arrays[f"level_{i}"] = np.asarray(img.resize((s, s), Image.BILINEAR))
+    save("mipchain", **arrays)
+
+
 def main():
     torch.set_num_threads(4)
     ref_models, ref_utils, ref_fp, ref_pe = load_reference_modules()
@@ -598,6 +612,7 @@ def main():
     g9_codec(ref_models, ref_utils)
     g10_trajectory(ref_models, ref_utils, ref_fp)
     g11_stored(ref_models, ref_utils, ref_fp)
+    g12_mipchain()
     assert not any("__pycache__" in d for d, _, _ in os.walk("/root/reference")), "bytecode written into reference"
 
 

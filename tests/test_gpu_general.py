@@ -289,7 +289,7 @@ def test_multilevel_field_trains_and_decodes(dev):
         losses.append(total)
     assert losses[-1] < 0.3 * losses[0], losses
     lo = -(2 ** 8 - 1) / 2 ** 9
-    assert all(float(g.min()) >= lo and float(g.max()) <= 0.5 for g in f.fp)
+    assert all(float(g.detach().min()) >= lo and float(g.detach().max()) <= 0.5 for g in f.fp)
     rec = f.decode(tile=100)                                                 # ragged tiles
     mlp_fin = O.MLPParams.from_state_dict({k: v.detach().cpu() for k, v in f.decoder.state_dict().items()})
     xr = _oracle_multilevel_input([g.detach().cpu() for g in f.fp], [[0, 0]], S, 3, 6, True)
@@ -385,3 +385,25 @@ def test_step_begin_and_adam_dev_entry_points(dev):
     assert torch.equal(a1.detach(), a2.detach()) and torch.equal(b1.detach(), b2.detach())
     assert [g["lr"] for g in o1.param_groups] == [g["lr"] for g in o2.param_groups]
     assert int(o2.state[a2]["step"].item()) == 12
+
+
+def test_rgbx_resize_is_the_references_mip_chain(dev):
+    """nic_rgbx_resample_axis + sampler.resize_coeffs against the golden levels Pillow made of the reference's sample image (tests/golden/mipchain.npz),
+    against the oracle's restatement on non-square / non-integer ratios, and through Settings.TF_MIP_FILTER in the host loop's RGBX pyramid"""
+    import os
+    from neural_image_compression_v2_amd.sampler import build_rgbx_pyramid, rgbx_interleave, rgbx_resize
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mipchain.npz"))
+
+    def unpack(t):
+        w = t.cpu().numpy().astype(np.uint32)
+        return np.stack([(w >> (8 * c)) & 255 for c in range(3)], axis=-1).astype(np.uint8)
+
+    img = torch.from_numpy(g["image"]).permute(2, 0, 1).contiguous().to(dev)              # [3, 128, 128] codes
+    pyr = build_rgbx_pyramid(img, 8)                                                        # default filter: the reference's
+    for i in range(1, 8):
+        assert np.array_equal(unpack(pyr[i].image), g[f"level_{i}"]), i
+    rng = np.random.default_rng(3)
+    for (H, W, oh, ow) in [(96, 160, 48, 80), (100, 60, 33, 17), (37, 53, 37, 20), (64, 64, 1, 1), (512, 512, 2, 2)]:
+        a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        lvl = rgbx_interleave(torch.from_numpy(a).permute(2, 0, 1).contiguous().to(dev))
+        assert np.array_equal(unpack(rgbx_resize(lvl, oh, ow)), O.pil_resize_bilinear(a, oh, ow)), (H, W, oh, ow)

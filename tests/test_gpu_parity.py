@@ -1245,7 +1245,8 @@ def test_targets_from_the_resident_image(dev):
 
 def test_device_sampler_and_rgbx_targets(dev):
     """SURVEY 8f rank 3, device side: (a) origins drawn by the kernel == the library's host twin == the oracle's restatement;
-    (b) the RGBX levels: level 0 = the image's codes interleaved, level k + 1 = the oracle's 2 x 2 box filter of level k;
+    (b) the RGBX levels: level 0 = the image's codes interleaved, level i = the reference's Resize chain (Pillow's BILINEAR resize of the original,
+    restated by the oracle) by default, or the 2 x 2 box filter level by level;
     (c) a training step whose targets are read from the RGBX image (one dword per sample) == the step on the materialised crop
     stack, in 2D (den 255) and 3D (den 256), both arithmetic modes, origins left on the device."""
     from neural_image_compression_v2_amd import _lib, fused
@@ -1261,14 +1262,18 @@ def test_device_sampler_and_rgbx_targets(dev):
         assert_exact(org, O.sampler_origins(1234567, step, 8, 2, rng), "device origins vs oracle")
     gen = torch.Generator().manual_seed(5)
     img = torch.randint(0, 256, (3, 96, 160), generator=gen, dtype=torch.uint8)
-    pyr = build_rgbx_pyramid(img.to(dev), 4)
-    lvl = img.permute(1, 2, 0).numpy()
-    for k, t_ in enumerate(pyr):
-        w = t_.image.cpu().numpy().astype(np.uint32)
-        got = np.stack([(w >> (8 * c)) & 255 for c in range(3)], axis=-1).astype(np.uint8)
-        assert got.shape == lvl.shape and np.array_equal(got, lvl), f"RGBX level {k}"
-        assert ((w >> 24) == 0).all()
-        lvl = O.rgbx_down2(lvl)
+    lvl0 = img.permute(1, 2, 0).numpy()
+    chain = O.reference_mip_chain(lvl0, 4)                             # the reference's transforms.Resize chain (Pillow's BILINEAR resize of the original)
+    for filt in ("resize", "box"):
+        pyr = build_rgbx_pyramid(img.to(dev), 4, mip_filter=filt)
+        lvl = lvl0
+        for k, t_ in enumerate(pyr):
+            w = t_.image.cpu().numpy().astype(np.uint32)
+            got = np.stack([(w >> (8 * c)) & 255 for c in range(3)], axis=-1).astype(np.uint8)
+            want = chain[k] if filt == "resize" else lvl
+            assert got.shape == want.shape and np.array_equal(got, want), f"RGBX level {k} ({filt})"
+            assert ((w >> 24) == 0).all()
+            lvl = O.rgbx_down2(lvl)
     cases = [(2, 1, 73, (12, 41, 25), (12, 21, 13), (96, 160), (32, 24), [[5, 64], [64, 0], [40, 136]], 255.0),
              (3, 4, 79, (12, 9, 9, 9), (12, 5, 5, 5), (32, 32, 32), (8, 8, 8), [[0, 3, 24], [17, 9, 1]], 256.0)]
     for dim, method, cin, s0, s1, isz, ext, orgs, den in cases:
@@ -1298,7 +1303,7 @@ def test_device_sampler_and_rgbx_targets(dev):
 
 def test_training_with_the_device_sampler_matches_the_oracle_loop(dev):
     """TF_DEVICE_SAMPLER: the product's loop with LOD / origins from the counter-based sampler and targets from the resident RGBX
-    mip pyramid against the oracle's loop fed the oracle's restatement of the same draws and the oracle's box-filter chain (mips on:
+    mip pyramid against the oracle's loop fed the oracle's restatement of the same draws and of the reference's Resize chain (mips on:
     LODs 0..4 occur): loss trajectory and final PSNR (peak 256) agree; no host RNG is consumed."""
     import random
     from neural_image_compression_v2_amd.image_compression import ImageCompression
@@ -1323,10 +1328,8 @@ def test_training_with_the_device_sampler_matches_the_oracle_loop(dev):
     fp = ic.train_models(ic.feature_pyramid, fused_step=True)
     assert torch.equal(torch.get_rng_state(), st_t) and random.getstate() == st_p, "the device sampler must not touch the host RNGs"
     losses_gpu = torch.stack(ic.loss_history).cpu().numpy()
-    # the oracle's datasets: level k + 1 = box filter of level k, value = code / 255
-    lv = [codes.permute(1, 2, 0).numpy()]
-    for _ in range(cfg.MAX_MIP_LEVEL):
-        lv.append(O.rgbx_down2(lv[-1]))
+    # the oracle's datasets: the reference's chain - level i = Resize(S // 2^i) of the original (Pillow BILINEAR) - value = code / 255
+    lv = O.reference_mip_chain(codes.permute(1, 2, 0).numpy(), cfg.MAX_MIP_LEVEL + 1)
     data = [torch.from_numpy(a.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1).contiguous() for a in lv]
     mp = O.create_pyramid_mip_levels(S, S // 4)
     cur, frozen, acc, losses_ref, lods = fp_ref, False, 0.0, [], []

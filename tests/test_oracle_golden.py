@@ -384,3 +384,35 @@ def test_stored_decode_fixture_and_in_kernel_dequantisation_formula():
             e = rn_exact(Fraction(float(n)) - Fraction(float(q)) * Fraction(float(d)))
             q2 = rn_exact(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
             assert q2 == n / d, (b, u)
+
+
+def test_reference_mip_chain_is_pillows_bilinear_resize():
+    """The reference builds its mip levels with ``transforms.Resize`` on a PIL image (image_compression.py:432-440): torchvision forwards to
+    ``Image.resize(size, BILINEAR)`` - third-party arithmetic (Pillow, src/libImaging/Resample.c).  The oracle's restatement
+    (``pil_resize_bilinear``) and the product's host-side coefficient table (``sampler.resize_coeffs``, the input of ``nic_rgbx_resample_axis``)
+    are pinned here against Pillow itself: bit-exact on random images, integer and non-integer ratios, down to one pixel."""
+    Image = pytest.importorskip("PIL.Image")
+    from neural_image_compression_v2_amd.sampler import resize_coeffs
+    rng = np.random.default_rng(0)
+    for (H, W, oh, ow) in [(64, 64, 32, 32), (64, 64, 16, 16), (256, 256, 128, 128), (256, 256, 1, 1), (100, 60, 50, 30), (37, 53, 9, 13), (64, 64, 2, 2),
+                           (96, 160, 12, 20)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(O.pil_resize_bilinear(img, oh, ow), ref), (H, W, oh, ow)
+        for n, o in ((W, ow), (H, oh)):
+            bounds, kk, ksize = resize_coeffs(n, o)
+            taps = O._pil_bilinear_coeffs(n, o)
+            assert ksize == int(math.ceil(max(n / o, 1.0))) * 2 + 1
+            for i, (lo, k) in enumerate(taps):
+                assert int(bounds[i, 0]) == lo and int(bounds[i, 1]) == len(k) and list(kk[i, :len(k)]) == k and not kk[i, len(k):].any()
+    chain = O.reference_mip_chain(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), 7)
+    assert [c.shape[0] for c in chain] == [64, 32, 16, 8, 4, 2, 1]
+
+
+def test_reference_mip_chain_golden(golden):
+    """tests/golden/mipchain.npz: a 128 x 128 crop of the reference's own sample image and the levels Pillow's BILINEAR resize makes of it (the call
+    torchvision's transforms.Resize forwards to; oracle/make_golden.py::g12_mipchain) - the oracle's restatement reproduces every level bit for bit"""
+    g = golden("mipchain")
+    chain = O.reference_mip_chain(g["image"], 8)
+    for i in range(1, 8):
+        assert np.array_equal(chain[i], g[f"level_{i}"]), i
