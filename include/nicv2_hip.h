@@ -209,6 +209,16 @@ int nic_decoder_general_forward(const nic_mlp *mlp, const float *x, int64_t n, i
 int nic_decoder_general_backward(const nic_mlp *mlp, const float *x, const float *dy, int64_t n, int cin, int hidden, float *dx,
                                  const nic_mlp_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- HIDDEN_LAYER_CHANNELS below 64 on the FUSED kernels (which are built for 64): a decoder with H hidden units IS the decoder with 64 units
+ *      whose extra units have zero weights and biases (pre-activation 0, GELU(0) = 0, zero outgoing weights: exact zero gradients).
+ *      nic_decoder_pad writes the zero-padded copies ([H, K] -> [hidden_padded, K'], the output layer [3, H] -> [3, hidden_padded]) into the
+ *      caller's `dst` tensors, the fused entry points run on them with desc->hidden = hidden_padded, nic_decoder_unpad copies the real block of
+ *      every padded gradient into the caller's gradient tensors (null entries of `dst` are skipped).  One launch each; fused.PaddedMlp does this
+ *      for every fused entry point of the Python side. */
+int nic_decoder_pad(const nic_mlp *src, int cin, int hidden, int hidden_padded, const nic_mlp_grads *dst, void *stream);
+int nic_decoder_unpad(const nic_mlp_grads *src_padded, int n_linear, int cin, int hidden, int hidden_padded, const nic_mlp_grads *dst,
+                      void *stream);
+
 /* ---- fused inference: encode + (optional noise) + decoder.  Replaces finally_decode_input_* + arc_decoder(x)
  *      inside decode_image (image_compression.py:313-345).  y = [N, 3]. */
 int nic_fused_forward(const nic_path_desc *desc, const float *g0, const float *g1, const int32_t *origins,

@@ -100,6 +100,8 @@ SIGNATURES = {
     "nic_decoder_general_workspace_bytes": (_SZ, [_L, _I, _I, _I, _I]),
     "nic_decoder_general_forward": (_I, [_M, _P, _L, _I, _I, _P, _P, _SZ, _P]),
     "nic_decoder_general_backward": (_I, [_M, _P, _P, _L, _I, _I, _P, _G, _P, _SZ, _P]),
+    "nic_decoder_pad": (_I, [_M, _I, _I, _I, _G, _P]),
+    "nic_decoder_unpad": (_I, [_G, _I, _I, _I, _I, _G, _P]),
     "nic_fused_forward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_u8": (_I, [_D, _P, _P, _P, _M, _P, _P, _P]),
     "nic_fused_forward_backward": (_I, [_D, _P, _P, _P, _M, _P, _P, _P, _P, _P, _P, _G, _P, _SZ, _P]),

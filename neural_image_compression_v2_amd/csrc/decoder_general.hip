@@ -244,6 +244,61 @@ inline int forward_chunk(const Plan& p, const nic_mlp* mlp, int NL, const float*
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Hidden widths below 64 on the FUSED kernels: a decoder with H hidden units is exactly the decoder with HP > H units whose extra units have
+// zero weights and biases - their pre-activations are 0, GELU(0) = 0 feeds nothing, and with zero outgoing weights their gradients are
+// exact zeros.  pad: [H, K] -> [HP, K'] (zero-filled); unpad: the real block of every padded gradient.  One launch each.
+// ---------------------------------------------------------------------------------------------------
+struct PadTable {
+    const float* src[2 * NIC_MAX_LINEAR];   // W_0, b_0, W_1, b_1, ..
+    float* dst[2 * NIC_MAX_LINEAR];
+    int rows_s[2 * NIC_MAX_LINEAR], cols_s[2 * NIC_MAX_LINEAR];   // the SMALL shape (biases: cols 1)
+    int rows_l[2 * NIC_MAX_LINEAR], cols_l[2 * NIC_MAX_LINEAR];   // the LARGE (padded) shape
+    int first[2 * NIC_MAX_LINEAR + 1];      // first thread index of tensor t (over the shape the launch walks)
+    int count;
+};
+// GROW: walk the large tensors, read the small ones (zero outside); else walk the small tensors, read the large ones
+template <bool GROW>
+__global__ void __launch_bounds__(256) pad_kernel(const PadTable t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.first[t.count]) return;
+    int k = 0;
+    while (k + 1 < t.count && i >= t.first[k + 1]) ++k;
+    const int e = i - t.first[k];
+    const int cw = GROW ? t.cols_l[k] : t.cols_s[k];
+    const int r = e / cw, c = e - r * cw;
+    if (GROW) t.dst[k][e] = (r < t.rows_s[k] && c < t.cols_s[k]) ? t.src[k][r * t.cols_s[k] + c] : 0.f;
+    else t.dst[k][e] = t.src[k][r * t.cols_l[k] + c];
+}
+
+inline int pad_launch(bool grow, const float* const* small_w, const float* const* small_b, float* const* small_w_out, float* const* small_b_out,
+                      const float* const* large_w, const float* const* large_b, float* const* large_w_out, float* const* large_b_out, int NL, int cin, int H,
+                      int HP, hipStream_t s) {
+    PadTable t = {};
+    int n = 0, total = 0;
+    for (int l = 0; l < NL; ++l) {
+        const int Ks = l == 0 ? cin : H, Kl = l == 0 ? cin : HP, Ns = l == NL - 1 ? 3 : H, Nl = l == NL - 1 ? 3 : HP;
+        for (int b = 0; b < 2; ++b) {
+            const float* src = grow ? (b ? small_b[l] : small_w[l]) : (b ? large_b[l] : large_w[l]);
+            float* dst = grow ? (b ? large_b_out[l] : large_w_out[l]) : (b ? small_b_out[l] : small_w_out[l]);
+            if (!dst) continue;                                   // a gradient the caller does not want
+            if (!src) return NIC_E_NULL;
+            t.src[n] = src; t.dst[n] = dst;
+            t.rows_s[n] = Ns; t.cols_s[n] = b ? 1 : Ks;
+            t.rows_l[n] = Nl; t.cols_l[n] = b ? 1 : Kl;
+            t.first[n] = total;
+            total += grow ? t.rows_l[n] * t.cols_l[n] : t.rows_s[n] * t.cols_s[n];
+            ++n;
+        }
+    }
+    t.first[n] = total;
+    t.count = n;
+    if (n == 0) return NIC_OK;
+    if (grow) hipLaunchKernelGGL(pad_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL(pad_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, t);
+    return (int)hipGetLastError();
+}
+
 }  // namespace general
 }  // namespace nic
 
@@ -321,6 +376,22 @@ int nic_decoder_general_backward(const nic_mlp* mlp, const float* x, const float
                            grads->b[l]);
     }
     return (int)hipGetLastError();
+}
+
+int nic_decoder_pad(const nic_mlp* src, int cin, int hidden, int hidden_padded, const nic_mlp_grads* dst, void* stream) {
+    int NL = 0;
+    if (!mlp_general_ok(src, NL) || !dst) return NIC_E_NULL;
+    if (cin < 1 || hidden < 1 || hidden_padded < hidden) return NIC_E_ARG;
+    for (int l = 0; l < NL; ++l)
+        if (!dst->w[l] || !dst->b[l]) return NIC_E_NULL;
+    return pad_launch(true, src->w, src->b, nullptr, nullptr, nullptr, nullptr, dst->w, dst->b, NL, cin, hidden, hidden_padded, (hipStream_t)stream);
+}
+
+int nic_decoder_unpad(const nic_mlp_grads* src_padded, int n_linear, int cin, int hidden, int hidden_padded, const nic_mlp_grads* dst, void* stream) {
+    if (!src_padded || !dst) return NIC_E_NULL;
+    if (n_linear < 2 || n_linear > NIC_MAX_LINEAR || cin < 1 || hidden < 1 || hidden_padded < hidden) return NIC_E_ARG;
+    return pad_launch(false, nullptr, nullptr, dst->w, dst->b, src_padded->w, src_padded->b, nullptr, nullptr, n_linear, cin, hidden, hidden_padded,
+                      (hipStream_t)stream);
 }
 
 }  // extern "C"

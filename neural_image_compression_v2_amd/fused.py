@@ -246,6 +246,45 @@ def check_mlp(params: Sequence[torch.Tensor], cin: int, hidden: int) -> List[tor
     return out
 
 
+FUSED_HIDDEN = 64          # the hidden width the fused kernels are built for
+
+
+class PaddedMlp:
+    """HIDDEN_LAYER_CHANNELS below 64 on the fused kernels: zero-padded copies of the decoder's parameters (``nic_decoder_pad``) are what the
+    kernel reads, with ``desc.hidden = 64``; the real block of every padded gradient is copied back (``nic_decoder_unpad``).  Exactly the
+    narrower decoder: the extra hidden units have zero weights and biases - pre-activation 0, GELU(0) = 0 - and zero outgoing weights, so they
+    contribute nothing forward and receive exact zero gradients.  One small launch before and one after the fused step; buffers are persistent
+    (``StepPlan`` keeps one), nothing is allocated per step."""
+
+    def __init__(self, params: Sequence[torch.Tensor], cin: int, hidden: int, want_grads: bool):
+        self.real = list(params)
+        self.cin, self.hidden, self.nl = int(cin), int(hidden), len(params) // 2
+        dev = params[0].device
+        HP = FUSED_HIDDEN
+        shapes = [(HP, cin), (HP,)] + [(HP, HP), (HP,)] * (self.nl - 2) + [(3, HP), (3,)]
+        self.params = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+        self.grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes] if want_grads else None
+        self.m_real = _mlp_struct(self.real)
+        self.m = _mlp_struct(self.params)
+        self.as_dst = _grads_struct(self.params)
+        self.gs = _grads_struct(self.grads) if want_grads else None
+        self.dev = dev
+
+    @staticmethod
+    def maybe(geo: "PathGeometry", params: Sequence[torch.Tensor], want_grads: bool) -> Optional["PaddedMlp"]:
+        """None when the decoder already has the kernels' width (or is wider: the C side answers NIC_E_UNSUPPORTED and the caller falls back)"""
+        return PaddedMlp(params, geo.cin, geo.hidden, want_grads) if 1 <= int(geo.hidden) < FUSED_HIDDEN else None
+
+    def pad(self) -> None:
+        _lib.check(_lib.load().nic_decoder_pad(ctypes.byref(self.m_real), self.cin, self.hidden, FUSED_HIDDEN, ctypes.byref(self.as_dst),
+                                               _lib.stream_ptr(self.dev)), "nic_decoder_pad")
+
+    def unpad(self, dst_grads: Sequence[Optional[torch.Tensor]]) -> None:
+        gd = _grads_struct(dst_grads)
+        _lib.check(_lib.load().nic_decoder_unpad(ctypes.byref(self.gs), self.nl, self.cin, self.hidden, FUSED_HIDDEN, ctypes.byref(gd),
+                                                 _lib.stream_ptr(self.dev)), "nic_decoder_unpad")
+
+
 # ------------------------------------------------------------------------------------------------------
 # plain calls
 # ------------------------------------------------------------------------------------------------------
@@ -295,7 +334,11 @@ def fused_forward(geo: PathGeometry, g0, g1, coord, params, noise: Optional[torc
             raise ValueError("noise must be [N, Cin]")
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0.device)
     d = geo.to_desc(g0, g1, origins_aligned(geo, coord))
-    m = _mlp_struct(params)
+    pad = PaddedMlp.maybe(geo, params, False)
+    if pad is not None:
+        pad.pad()
+        d.hidden = FUSED_HIDDEN
+    m = pad.m if pad is not None else _mlp_struct(params)
     _lib.check(_lib.load().nic_fused_forward(ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m),
                                              _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(y),
                                              _lib.stream_ptr(g0.device)), "nic_fused_forward")
@@ -323,7 +366,11 @@ def fused_forward_u8(geo: PathGeometry, g0_u8, g1_u8, coord, params, out: str = 
     y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=g0_u8.device) if out != "uint8" else None
     yq = torch.empty(geo.n_samples, 3, dtype=torch.uint8, device=g0_u8.device) if out != "float" else None
     d = geo.to_desc(g0_u8, g1_u8, origins_aligned(geo, coord))
-    m = _mlp_struct(params)
+    pad = PaddedMlp.maybe(geo, params, False)
+    if pad is not None:
+        pad.pad()
+        d.hidden = FUSED_HIDDEN
+    m = pad.m if pad is not None else _mlp_struct(params)
     _lib.check(_lib.load().nic_fused_forward_u8(ctypes.byref(d), _lib.ptr(g0_u8), _lib.ptr(g1_u8), _lib.ptr(org), ctypes.byref(m),
                                                 _lib.ptr(y), _lib.ptr(yq), _lib.stream_ptr(g0_u8.device)), "nic_fused_forward_u8")
     return y if out == "float" else (yq if out == "uint8" else (y, yq))
@@ -437,8 +484,12 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     lib = _lib.load()
     ws_bytes = int(lib.nic_workspace_bytes(ctypes.byref(d)))
     ws = _lib.workspace(dev, ws_bytes)
-    m = _mlp_struct(params)
-    gs = _grads_struct(gm)
+    pad = PaddedMlp.maybe(geo, params, True)
+    if pad is not None:
+        pad.pad()
+        d.hidden = FUSED_HIDDEN
+    m = pad.m if pad is not None else _mlp_struct(params)
+    gs = pad.gs if pad is not None else _grads_struct(gm)
     if events is not None:                   # (start, end) torch.cuda.Event pair recorded on the launch stream
         events[0].record(torch.cuda.current_stream(dev))
     noise_p = _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None)
@@ -452,6 +503,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
             ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m), noise_p, _lib.ptr(target), _lib.ptr(y),
             _lib.ptr(views[0]), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
             "nic_fused_forward_backward")
+    if pad is not None:
+        pad.unpad(gm)
     if events is not None:
         events[1].record(torch.cuda.current_stream(dev))
     return StepOutput(views[0][0], y, gg0, gg1, gm, flat)
@@ -489,8 +542,11 @@ class StepPlan:
         self.gm = [views[1 + i].view(self.params[i].shape) for i in range(2 * nl)]
         self.gg0, self.gg1 = views[1 + 2 * nl].view(self.g0.shape), views[2 + 2 * nl].view(self.g1.shape)
         self.d = geo.to_desc(self.g0, self.g1, False)
-        self.m = _mlp_struct(self.params)
-        self.gs = _grads_struct(self.gm)
+        self.pad = PaddedMlp.maybe(geo, self.params, True)           # hidden widths below 64: the kernel reads zero-padded copies
+        if self.pad is not None:
+            self.d.hidden = FUSED_HIDDEN
+        self.m = self.pad.m if self.pad is not None else _mlp_struct(self.params)
+        self.gs = self.pad.gs if self.pad is not None else _grads_struct(self.gm)
         self.timg = target.to_struct(geo, [[0] * geo.dim] * geo.num_crops)
         self.target = target
         self.lib = _lib.load()
@@ -540,10 +596,14 @@ class StepPlan:
                 self.flat.zero_()
             self.clean = False               # set again by whoever zeroes the grid gradients (FusedAdam.zero_grad_in_step: in its own launch)
             ws = _lib.workspace(dev, int(self.lib.nic_workspace_bytes(ctypes.byref(d))))
+            if self.pad is not None:
+                self.pad.pad()
             _lib.check(self.lib.nic_fused_forward_backward_img(
                 ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
                 self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
                 "nic_fused_forward_backward_img")
+            if self.pad is not None:
+                self.pad.unpad(self.gm)
         return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)
 
     def launch_dev(self, origins_dev: torch.Tensor, step_dev_ptr: int, loss_slot: torch.Tensor, ws: torch.Tensor, noise_mode: int, noise_seed: int,
@@ -555,10 +615,14 @@ class StepPlan:
         d.noise_mode = int(noise_mode)
         d.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
         d.noise_offset = int(noise_base) & 0xFFFFFFFFFFFFFFFF
+        if self.pad is not None:
+            self.pad.pad()
         _lib.check(self.lib.nic_fused_forward_backward_img_dev(
             ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(origins_dev), ctypes.byref(self.m), ctypes.byref(self.timg),
             _lib.ptr(loss_slot), _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), ctypes.c_void_p(step_dev_ptr), _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr(self.dev)), "nic_fused_forward_backward_img_dev")
+        if self.pad is not None:
+            self.pad.unpad(self.gm)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -594,11 +658,17 @@ class FusedGridMLP(torch.autograd.Function):
         d = geo.to_desc(g0c, g1c)
         lib = _lib.load()
         ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(ctypes.byref(d))))
-        m, gs = _mlp_struct(pc), _grads_struct(gm)
+        pad = PaddedMlp.maybe(geo, pc, True)
+        if pad is not None:
+            pad.pad()
+            d.hidden = FUSED_HIDDEN
+        m, gs = (pad.m, pad.gs) if pad is not None else (_mlp_struct(pc), _grads_struct(gm))
         noise = ctx.noise if geo.noise_mode == NIC_NOISE_TENSOR else None
         _lib.check(lib.nic_fused_backward_dy(ctypes.byref(d), _lib.ptr(g0c), _lib.ptr(g1c), _lib.ptr(ctx.org), ctypes.byref(m),
                                              _lib.ptr(noise), _lib.ptr(dy), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs),
                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_backward_dy")
+        if pad is not None:
+            pad.unpad(gm)
         need = ctx.needs_input_grad
         return (gg0 if need[0] else None, gg1 if need[1] else None, None, None, None, *[gm[i] if need[5 + i] else None for i in range(len(gm))])
 

@@ -154,11 +154,11 @@ def _image(S, D):
 
 
 FLAG_CASES = [
-    dict(IMAGE_SIZE=512, HIDDEN_LAYER_CHANNELS=32),                                                      # H = 32, split products asked for: no fused kernel
+    dict(IMAGE_SIZE=512, HIDDEN_LAYER_CHANNELS=96),                                                      # wider than the fused kernels' 64
     dict(IMAGE_SIZE=512, HIDDEN_LAYER_CHANNELS=128, FEATURE_PYRAMID_CHANNELS=8, PE_CHANNELS=4, TF_USE_TRI_PE=False),
     dict(IMAGE_SIZE=512, DECODER_LINEAR_LAYERS=4, FEATURE_PYRAMID_CHANNELS=20),                          # a depth and a channel count outside every list
     dict(IMAGE_SIZE=32, IMAGE_DIMENSION=3, COMPRESSION_METHOD=4, CROP_MIP_LEVEL=4, HIDDEN_LAYER_CHANNELS=96),
-    dict(IMAGE_SIZE=32, IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, CROP_MIP_LEVEL=4, HIDDEN_LAYER_CHANNELS=32, FEATURE_PYRAMID_CHANNELS=4),
+    dict(IMAGE_SIZE=32, IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, CROP_MIP_LEVEL=4, HIDDEN_LAYER_CHANNELS=80, FEATURE_PYRAMID_CHANNELS=4),
 ]
 
 
@@ -407,3 +407,72 @@ def test_rgbx_resize_is_the_references_mip_chain(dev):
         a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         lvl = rgbx_interleave(torch.from_numpy(a).permute(2, 0, 1).contiguous().to(dev))
         assert np.array_equal(unpack(rgbx_resize(lvl, oh, ow)), O.pil_resize_bilinear(a, oh, ow)), (H, W, oh, ow)
+
+
+
+# ------------------------------------------------------------------------------------------------------
+# HIDDEN_LAYER_CHANNELS below 64 on the FUSED kernels: zero-padded parameters (fused.PaddedMlp, nic_decoder_pad / _unpad)
+# ------------------------------------------------------------------------------------------------------
+PAD_CASES = [
+    # dim, method, hidden, n_linear, mode kwargs, tolerance (y, grads)
+    (2, 1, 32, 3, dict(), 1e-5, 2e-5),                              # fp32 MFMA kernel
+    (2, 1, 32, 3, dict(split_bf16=True), 2e-5, 5e-5),               # fused_train16
+    (2, 1, 48, 5, dict(split_bf16=True), 2e-5, 1e-4),               # fused_mlpn, 5 layers
+    (2, 1, 32, 3, dict(bf16=True), None, None),                     # fused_q16 (held to the emulating oracle)
+    (3, 3, 16, 3, dict(), 1e-5, 2e-5),
+    (3, 4, 32, 3, dict(bf16=True), None, None),
+    (3, 4, 1, 3, dict(), 1e-5, 2e-5),                               # a single hidden unit
+]
+
+
+@pytest.mark.parametrize("dim,method,H,NL,kw,tol_y,tol_g", PAD_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else ",".join(v) or "fp32")
+def test_fused_kernels_serve_narrower_decoders_by_zero_padding(dev, dim, method, H, NL, kw, tol_y, tol_g):
+    """fused step and fused decode with HIDDEN_LAYER_CHANNELS = H < 64 against the oracle's H-wide decoder: outputs, loss, grid gradients and all
+    decoder gradients (shapes [H, ..]: the padded rows never reach the caller); plain-bf16 cases against the precision-emulating oracle"""
+    from neural_image_compression_v2_amd import _lib, fused
+    g = torch.Generator().manual_seed(50 + H + NL + dim)
+    base = 16
+    fp, _ = O.create_pyramid(base, 12, 8, no_mip=True, generator=g, dim=dim)
+    g0, g1 = fp[0].detach(), fp[1].detach()
+    cin = O.decoder_input_channels(12, 6, dim, method)
+    mlp = O.init_mlp(cin, H, generator=g, n_linear=NL)
+    extent = (24, 20) if dim == 2 else (12, 8, 10)
+    origins = [[3, 5, 2][:dim], [30, 0, 17][:dim]]
+    n = 2 * int(np.prod(extent))
+    target = torch.rand(n, 3, generator=g)
+    noise = O.kernel_noise(n, cin, 8, seed=11, offset=5, quarter=bool(kw.get("bf16")))
+    emulate = "bf16" if kw.get("bf16") else None
+    ref = O.forward_backward(g0, g1, mlp, origins, extent, 0.25, 0, target, noise, 6, method=method, **({"emulate": emulate} if emulate else {}))
+    geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=2, hidden=H,
+                             noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=11, noise_offset=5, **kw)
+    params = [t.to(dev) for t in mlp.tensors()]
+    out = fused.fused_forward_backward(geo, g0.to(dev), g1.to(dev), origins, params, target.to(dev), want_y=True)
+    ty, tg = (tol_y, tol_g) if tol_y is not None else (2e-3, 3e-3)
+    assert relmax(out.y, ref.y) < ty and relmax(out.loss.reshape(()), torch.as_tensor(ref.loss).reshape(())) < max(ty, 1e-5)
+    assert relmax(out.grad_g0, ref.grad_g0) < tg and relmax(out.grad_g1, ref.grad_g1) < tg
+    for i, (a, b) in enumerate(zip(out.grad_mlp, ref.grad_mlp)):
+        assert tuple(a.shape) == tuple(b.shape) and relmax(a, b) < tg, (i, relmax(a, b))
+    # decode (no noise): the forward kernels
+    geo_d = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=2, hidden=H, **kw)
+    y = fused.fused_forward(geo_d, g0.to(dev), g1.to(dev), origins, params)
+    x = O.create_decoder_input(g0, g1, origins, extent, 0.25, 0, 6, method=method)
+    assert relmax(y, O.mlp_forward(x, mlp)) < (5e-3 if kw.get("bf16") else 2e-5)
+
+
+def test_host_loop_with_32_hidden_units_stays_on_the_fused_kernels(dev):
+    """HIDDEN_LAYER_CHANNELS = 32 (var2.py:72): the product loop keeps the fused step and decode (no fallback), trains, and a captured run equals it"""
+    from neural_image_compression_v2_amd.image_compression import ImageCompression
+    from neural_image_compression_v2_amd.var2 import Settings
+    res = {}
+    for mode in ("host", "graph"):
+        cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=40, NUM_CROPS=2, TF_NO_MIP=True, HIDDEN_LAYER_CHANNELS=32, TF_DEVICE_SAMPLER=True)
+        ic = ImageCompression(cfg, dev, seed=0)
+        ic.set_images([torch.round(_image(512, 2) * 255).to(torch.uint8)])
+        p0 = float(ic.psnr(ic.feature_pyramid))
+        fp = ic.train_models(ic.feature_pyramid) if mode == "host" else ic.train_models_graph(ic.feature_pyramid, steps_per_graph=4)
+        assert not getattr(ic, "_no_fused_kernel", False) and not getattr(ic, "_no_fused_decode", False)
+        assert ic.decoder.decoder[0].weight.shape == (32, 73) and ic.decoder.decoder[0].weight.grad.shape == (32, 73)
+        res[mode] = (torch.stack([l.reshape(()) for l in ic.loss_history]).cpu(), float(ic.psnr(fp)))
+        assert res[mode][1] > p0 + 1.0
+    rel = float(((res["host"][0] - res["graph"][0]).abs() / res["host"][0]).max())
+    assert rel < 2e-3 and abs(res["host"][1] - res["graph"][1]) < 0.02
