@@ -196,7 +196,7 @@ def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic
     common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": fl, "bytes_per_sample": byt,
               "samples_per_launch": n_launch, "kernel": kernel_name(dim, method, precision, n_linear)}
     if traffic is not None:
-        common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of round 2's build of the split kernel, not measured in this run)"
+        common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of this tree's split kernel, profiles/r03_z_pmc.csv; not measured in this run)"
     if stats is not None:
         common["stats"] = stats
     hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
