@@ -1,56 +1,69 @@
 // ColorDecoder of ANY width and depth on explicit [n, Cin] inputs (image_compression.py:54-68: DECODER_INPUT_CHANNELS and
 // HIDDEN_LAYER_CHANNELS are reference flags, var2.py:72,114-118) - the layer-wise fp32 path behind nic_decoder_general_forward /
 // _backward.  The fused kernels specialise the reference's defaults (H = 64, the listed channel counts, 3 or 5 layers); every other
-// configuration of the reference's flags runs here: one LDS-tiled fp32 product kernel per layer and direction, activations kept in a
+// configuration of the reference's flags runs here: one LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32) product kernel per layer and direction, activations kept in a
 // caller-owned workspace the way autograd keeps them, the sample axis walked in chunks sized to stay in L2 / Infinity Cache.
 //
 //   forward   A_k = gelu(A_{k-1} W_k^T + b_k)  (D_k = gelu'(.) kept when training),  y = sigmoid(A_last W_out^T + b_out)
 //   backward  dZ_out = dy y (1 - y);  dA_{k} = dZ_{k+1} W_{k+1};  dZ_k = dA_k D_k;  dW_k = dZ_k^T A_{k-1};  db_k = column sums of dZ_k
 // Weight gradients: every workgroup sums a slice of the chunk's rows into ITS slot of the workspace (slots accumulate over the chunks,
 // launches of one stream are ordered), one fixed-order reduction at the end: results are bit-stable run to run.
-// Arithmetic: fp32 fmaf chains along the reduction index, GELU / sigmoid of nic_device.hpp (the fused kernels' own).
+// Arithmetic: fp32 MFMA = exact fmaf chains along the reduction index, GELU / sigmoid of nic_device.hpp (the fused kernels' own).
 #include "nic_device.hpp"
 
 namespace nic {
 namespace general {
 
-constexpr int TM = 64, TN = 64, TK = 16, LDT = TM + 4;
+constexpr int TM = 64, TN = 64, TK = 32, LDT = TM + 4;
+typedef float f32x16v __attribute__((ext_vector_type(16)));
 
-// acc[r][c] += sum over the reduction range [k0, k1) of a(row 4 ty + r, k) * b(col 4 tx + c, k).  la / lb return 0 outside their operand.
-// AFAST / BFAST: consecutive lanes walk the reduction index (the operand is contiguous along it) instead of the row / column index.
-template <bool AFAST, bool BFAST, class LoadA, class LoadB, class Side>
-__device__ __forceinline__ void tile_product(int k0, int k1, LoadA&& la, LoadB&& lb, float (&acc)[4][4], Side&& side) {
+// A 64 x 64 output tile per 256-thread workgroup on the fp32 matrix pipe: wave w owns the 32 x 32 sub-tile (w >> 1, w & 1) and runs
+// v_mfma_f32_32x32x2_f32 over k-steps of 32 staged through two LDS tiles ([32][68] floats, k-major; the next step's global loads are issued before
+// this step's products).  The fp32 MFMA is an exact fmaf chain along k
+// (MI355X_MICROARCH: bitwise), so the results are those of the scalar loop - at the pipe's 256 FLOP / cycle / CU instead of the VALU's LDS-bound ~ 20 %.
+//   acc += sum over the reduction range [k0, k1) of a(row, k) * b(col, k);  la / lb return 0 outside their operand.
+//   register r of lane l of a wave: row 32 (w >> 1) + (r & 3) + 8 (r >> 2) + 4 (l >> 5), column 32 (w & 1) + (l & 31)   (tile_row / tile_col)
+// AFAST / BFAST: consecutive lanes of the LOADS walk the reduction index (the operand is contiguous along it) instead of the row / column index.
+// side_sum (nullable): += every A operand this lane feeds the pipe (the weight kernel's bias gradient: column sums of dZ).
+__device__ __forceinline__ int tile_row(int r) { return 32 * ((threadIdx.x >> 6) >> 1) + (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
+__device__ __forceinline__ int tile_col() { return 32 * ((threadIdx.x >> 6) & 1) + (threadIdx.x & 31); }
+
+template <bool AFAST, bool BFAST, class LoadA, class LoadB>
+__device__ __forceinline__ void tile_product(int k0, int k1, LoadA&& la, LoadB&& lb, f32x16v& acc, float* side_sum) {
     __shared__ __attribute__((aligned(16))) float As[TK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    for (int kb = k0; kb < k1; kb += TK) {
-        float av[4], bv[4];
+    constexpr int NE = TK * TM / 256;                     // elements of a tile per thread and operand
+    constexpr int KSH = TK == 32 ? 5 : 4;                 // log2(TK)
+    static_assert(TK == (1 << KSH) && TM == 64 && TN == 64, "tile shape");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int arow = 32 * (wave >> 1) + (lane & 31), bcol = 32 * (wave & 1) + (lane & 31), half = lane >> 5;
+    float av[NE], bv[NE];
+    auto fetch = [&](int kb) {                            // global -> registers (the next tile's loads are in flight while this one multiplies)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NE; ++r) {
             const int e = tid + 256 * r;
-            const int ak = AFAST ? (e & 15) : (e >> 6), ai = AFAST ? (e >> 4) : (e & 63);
-            const int bk = BFAST ? (e & 15) : (e >> 6), bj = BFAST ? (e >> 4) : (e & 63);
+            const int ak = AFAST ? (e & (TK - 1)) : (e >> 6), ai = AFAST ? (e >> KSH) : (e & 63);
+            const int bk = BFAST ? (e & (TK - 1)) : (e >> 6), bj = BFAST ? (e >> KSH) : (e & 63);
             av[r] = kb + ak < k1 ? la(ai, kb + ak) : 0.f;
             bv[r] = kb + bk < k1 ? lb(bj, kb + bk) : 0.f;
         }
+    };
+    if (k0 < k1) fetch(k0);
+    for (int kb = k0; kb < k1; kb += TK) {
         __syncthreads();                                  // the previous tile has been consumed
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NE; ++r) {
             const int e = tid + 256 * r;
-            As[AFAST ? (e & 15) : (e >> 6)][AFAST ? (e >> 4) : (e & 63)] = av[r];
-            Bs[BFAST ? (e & 15) : (e >> 6)][BFAST ? (e >> 4) : (e & 63)] = bv[r];
+            As[AFAST ? (e & (TK - 1)) : (e >> 6)][AFAST ? (e >> KSH) : (e & 63)] = av[r];
+            Bs[BFAST ? (e & (TK - 1)) : (e >> 6)][BFAST ? (e >> KSH) : (e & 63)] = bv[r];
         }
         __syncthreads();
+        if (kb + TK < k1) fetch(kb + TK);
 #pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
-            const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
-            side(a);
+        for (int kk = 0; kk < TK / 2; ++kk) {             // A[i][k] in lane (i, k half), B[k][j] in lane (j, k half): two k per instruction
+            const float a = As[2 * kk + half][arow], b = Bs[2 * kk + half][bcol];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            if (side_sum) *side_sum += a;
         }
     }
 }
@@ -64,30 +77,27 @@ __global__ void __launch_bounds__(256) linear_forward_kernel(const float* __rest
                                                              const float* __restrict__ dy) {
     const int64_t i0 = (int64_t)blockIdx.x * TM;
     const int j0 = blockIdx.y * TN;
-    float acc[4][4] = {};
+    f32x16v acc = {};
     tile_product<true, true>(0, K,
         [&](int i, int k) { return i0 + i < m ? in[(i0 + i) * K + k] : 0.f; },
-        [&](int j, int k) { return j0 + j < N ? W[(int64_t)(j0 + j) * K + k] : 0.f; }, acc, [](const float (&)[4]) {});
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        [&](int j, int k) { return j0 + j < N ? W[(int64_t)(j0 + j) * K + k] : 0.f; }, acc, nullptr);
+    const int j = j0 + tile_col();
+    if (j >= N) return;
+    const float bj = bias[j];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t i = i0 + 4 * ty + r;
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + tile_row(r);
         if (i >= m) continue;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = j0 + 4 * tx + c;
-            if (j >= N) continue;
-            const float z = acc[r][c] + bias[j];
-            if (ACT == ACT_GELU) {
-                float a, d;
-                gelu_and_grad(z, a, d);
-                out_a[i * N + j] = a;
-                if (out_d) out_d[i * N + j] = d;
-            } else {
-                const float y = sigmoid_f(z);
-                if (ACT == ACT_SIGMOID) out_a[i * N + j] = y;
-                else out_a[i * N + j] = dy[i * N + j] * y * (1.0f - y);         // dZ_out
-            }
+        const float z = acc[r] + bj;
+        if (ACT == ACT_GELU) {
+            float a, d;
+            gelu_and_grad(z, a, d);
+            out_a[i * N + j] = a;
+            if (out_d) out_d[i * N + j] = d;
+        } else {
+            const float y = sigmoid_f(z);
+            if (ACT == ACT_SIGMOID) out_a[i * N + j] = y;
+            else out_a[i * N + j] = dy[i * N + j] * y * (1.0f - y);         // dZ_out
         }
     }
 }
@@ -97,21 +107,17 @@ __global__ void __launch_bounds__(256) linear_backward_input_kernel(const float*
                                                                     int64_t m, int N, int K, float* __restrict__ out) {
     const int64_t i0 = (int64_t)blockIdx.x * TM;
     const int j0 = blockIdx.y * TN;
-    float acc[4][4] = {};
+    f32x16v acc = {};
     tile_product<true, false>(0, N,
         [&](int i, int o) { return i0 + i < m ? dz[(i0 + i) * N + o] : 0.f; },
-        [&](int j, int o) { return j0 + j < K ? W[(int64_t)o * K + j0 + j] : 0.f; }, acc, [](const float (&)[4]) {});
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        [&](int j, int o) { return j0 + j < K ? W[(int64_t)o * K + j0 + j] : 0.f; }, acc, nullptr);
+    const int j = j0 + tile_col();
+    if (j >= K) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t i = i0 + 4 * ty + r;
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + tile_row(r);
         if (i >= m) continue;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = j0 + 4 * tx + c;
-            if (j >= K) continue;
-            out[i * K + j] = D ? acc[r][c] * D[i * K + j] : acc[r][c];
-        }
+        out[i * K + j] = D ? acc[r] * D[i * K + j] : acc[r];
     }
 }
 
@@ -122,35 +128,31 @@ __global__ void __launch_bounds__(256) linear_backward_weight_kernel(const float
     const int o0 = blockIdx.y * TM, k0 = blockIdx.z * TN;
     const int64_t r0 = (int64_t)s * rows_per_slice;
     const int64_t r1 = r0 + rows_per_slice < m ? r0 + rows_per_slice : m;
-    float acc[4][4] = {};
-    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    const bool do_db = blockIdx.z == 0 && tx == 0;
+    f32x16v acc = {};
+    float dbacc = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool do_db = blockIdx.z == 0 && (wave & 1) == 0;          // the waves of column block 0: each A operand (a dZ value) counted once
     if (r0 < r1)
         tile_product<false, false>(0, (int)(r1 - r0),
             [&](int i, int r) { return o0 + i < N ? dz[(r0 + r) * N + o0 + i] : 0.f; },
-            [&](int j, int r) { return k0 + j < K ? a[(r0 + r) * K + k0 + j] : 0.f; }, acc,
-            [&](const float (&av)[4]) {
-                if (do_db) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dbacc[r] += av[r];
-                }
-            });
+            [&](int j, int r) { return k0 + j < K ? a[(r0 + r) * K + k0 + j] : 0.f; }, acc, do_db ? &dbacc : nullptr);
     float* slot = slots + (int64_t)s * slot_stride;
+    const int k = k0 + tile_col();
+    if (k < K) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 4 * ty + r;
-        if (o >= N) continue;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = k0 + 4 * tx + c;
-            if (k >= K) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + tile_row(r);
+            if (o >= N) continue;
             float* d = slot + (int64_t)o * K + k;
-            *d = accumulate ? *d + acc[r][c] : acc[r][c];
+            *d = accumulate ? *d + acc[r] : acc[r];
         }
-        if (do_db) {
+    }
+    if (do_db) {                                                    // lane (i, half) summed the rows of k parity `half`: add the two halves
+        const float tot = dbacc + __shfl_down(dbacc, 32);
+        const int o = o0 + 32 * (wave >> 1) + lane;
+        if (lane < 32 && o < N) {
             float* d = slot + (int64_t)N * K + o;
-            *d = accumulate ? *d + dbacc[r] : dbacc[r];
+            *d = accumulate ? *d + tot : tot;
         }
     }
 }
@@ -201,8 +203,8 @@ inline Plan make_plan(int64_t n, int cin, int H, int NL, bool training) {
     p.off_d = p.off_a + (training ? NL - 1 : 2) * p.act_floats;       // inference: two ping-pong buffers, no derivatives
     p.off_dz = p.off_d + (training ? NL - 1 : 0) * p.act_floats;
     p.off_slots = p.off_dz + (training ? 2 : 0) * p.act_floats;
-    p.n_slots = (int)((rows + 1023) / 1024);
-    if (p.n_slots > 128) p.n_slots = 128;
+    p.n_slots = (int)((rows + 255) / 256);                            // slices of >= 256 rows: enough workgroups in flight for the narrow layers (H = 64: one tile per slice)
+    if (p.n_slots > 512) p.n_slots = 512;
     p.rows_per_slice = (int)round_up((rows + p.n_slots - 1) / p.n_slots, TK);
     int64_t off = 0;
     for (int l = 0; l < NL; ++l) {
