@@ -66,6 +66,14 @@ namespace nic {
 enum { SRC_ENCODE = 0, SRC_MEMORY = 1 };
 enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2, MODE_TRAIN_IMG = 3 };   // IMG: MSE against a resident image
 
+// Pin the GELU derivatives where the forward pass computes them (fused_q16.hpp::pin has the story): the compiler otherwise sinks the last steps of each
+// derivative to its use in the backward pass and carries three values per derivative through the round.  32-sample kernels, measured (interleaved A/B):
+// spilled registers method 3 130 -> 16 (split) / 115 -> 1 (fp32), method 4 112 -> 4, 2D 20 -> 0; 128^3 split steps 1.42 -> 0.94 ms (method 3), 1.04 -> 0.81
+// (method 4); the fp32 4K launch 4.58 -> 4.40 ms.  (fused_train16, which does not spill, LOSES 3.9 % with the same pin: there the sinking spreads vector
+// work into the backward pass.)
+#ifndef NIC_FK_PIN
+#define NIC_FK_PIN 1
+#endif
 struct FusedParams {
     nic_path_desc d;
     GridView g0, g1;
@@ -1256,6 +1264,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
                     f32x4_t aq4, dq4;
                     gelu_and_grad4(zq, aq4, dq4);
+                    if (TRAIN && NIC_FK_PIN) asm volatile("" : "+v"(dq4));      // keep the derivative, not the three values it is made of (fused_q16.hpp::pin)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         a1[to][4 * r4 + j] = aq4[j];
@@ -1327,6 +1336,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
                     const f32x4_t zq = {z[to][4 * r4], z[to][4 * r4 + 1], z[to][4 * r4 + 2], z[to][4 * r4 + 3]};
                     f32x4_t aq4, dq4;
                     gelu_and_grad4(zq, aq4, dq4);
+                    if (TRAIN && NIC_FK_PIN) asm volatile("" : "+v"(dq4));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         a2[to][4 * r4 + j] = aq4[j];

@@ -264,6 +264,10 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a[0][t], d[0][t]);
+#ifdef NIC_MLPN_PIN
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[0][t]));
+#endif
                 }
                 // ---------- hidden layers
                 lds_cf* const b_row = opaque(Bs + 4 * g);
@@ -284,6 +288,10 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a[k + 1][t], d[k + 1][t]);
+#ifdef NIC_MLPN_PIN
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[k + 1][t]));
+#endif
                 }
                 // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); training: the fragments
                 // of its input are also the image dW_out contracts with (the DZ region is free until the first dZ is stored)

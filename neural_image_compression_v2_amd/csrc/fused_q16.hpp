@@ -188,12 +188,46 @@ __device__ __forceinline__ bf16x8 cvt_pair(const f32x4& a, const f32x4& b) {    
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return cvt8(x);
 }
+// Materialise a packed fragment where it is written.  Left alone, the compiler SINKS the tail of a GELU derivative (z phi(z) + Phi(z), the rounding, the
+// packing) from the forward pass down to its use in the backward pass and keeps three fp32 intermediates per value alive across the whole round instead
+// of half a register: that - not the derivatives themselves - was what spilled 70 - 150 registers whenever all four layers' derivatives of the 5-layer
+// decoder were kept (found in the ISA: v_cvt_pk after the backward pass's MFMAs, fed by "Folded Reload"s).
+__device__ __forceinline__ void pin(bf16x8& f) {
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    asm volatile("" : "+v"(t));
+    f = __builtin_bit_cast(bf16x8, t);
+}
+// one row tile's four values -> half a fragment (two dwords), and the fragment of two halves
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 cvt_half(const f32x4& a) {
+    const f32x2 v0 = {a[0], a[1]}, v1 = {a[2], a[3]};
+    return u32x2{__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2)), __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2))};
+}
+__device__ __forceinline__ bf16x8 join_halves(const u32x2& lo, const u32x2& hi) { return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]}); }
 // the fp32 values of a packed fragment: elements 0..3 (lo = false) or 4..7 (lo = true)
 __device__ __forceinline__ f32x4 unpack4(const bf16x8& f, bool hi4) {
     const u32x4 w = __builtin_bit_cast(u32x4, f);
     const uint32_t a = hi4 ? w[2] : w[0], b = hi4 ? w[3] : w[1];
     return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u), __builtin_bit_cast(float, b << 16),
                  __builtin_bit_cast(float, b & 0xFFFF0000u)};
+}
+// GELU derivatives as 8-bit fixed point (5-layer decoders: four hidden layers' derivatives in the 16 registers two layers take as bf16): d in
+// [-0.129, 1.129] -> q = rne((d + 0.13) * 255 / 1.26) in 0 .. 255 (v_cvt_pk_u8_f32 rounds to nearest even and saturates: ab/micro/cvt_u8_probe.hip),
+// d' = q * (1.26 / 255) - 0.13: |d' - d| <= 0.0025 (bf16 keeps d to 0.002 near 1).  Restated by oracle/nic_oracle.py::quantize_gelu_grad_u8.
+__device__ __forceinline__ uint32_t pack_d8(const f32x4& d) {
+    uint32_t w = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d[i], 202.38095092773438f, 26.309524536132812f), (uint32_t)i, w);
+    // materialise the bytes HERE: left alone the compiler sinks the tail of the derivative (z phi(z) + Phi(z), the scaling, the packing) down to its
+    // use in the backward pass and keeps three fp32 intermediates per value alive across the whole round instead of one byte (130 spilled registers)
+    asm volatile("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ f32x4 unpack_d8(uint32_t w) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmaf((float)((w >> (8 * i)) & 255u), 0.004941176623106003f, -0.12999999523162842f);   // v_cvt_f32_ubyteN + fma
+    return r;
 }
 // acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
 template <int NT, bool ZERO = false, class LoadA>
@@ -487,6 +521,12 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
     barrier();
 }
 
+#ifndef NIC_Q16_PIN
+#define NIC_Q16_PIN 2        // pin the derivative fragments: 1 everywhere, 2 with 5 layers only (measured, interleaved A/B: pinning costs the 3-layer kernels 0.8 % in 2D, 2 % with method 4)
+#endif
+#ifndef NIC_Q16_D8_ONE
+#define NIC_Q16_D8_ONE 1
+#endif
 #ifndef NIC_Q16_PREADD
 #define NIC_Q16_PREADD 2
 #endif
@@ -526,10 +566,18 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     // LDS image as the very fragments the forward pass multiplied (same operands, same order: the same pre-activations bit for bit).
     // 20 more MFMAs and ~300 vector instructions per round buy 16 registers: with them the 5-layer kernel spilled 70 - 150 registers
     // and moved 9.8 GB of scratch traffic per 4K launch (profiles/r03_c0_pmc.csv: FETCH_SIZE 1.8 GB, WRITE_SIZE 6.0 GB against 0.10 / 0.16 GB).
+    // 5 layers, second form (default): ALL derivatives kept, as 8-bit fixed point (pack_d8: 4 registers per layer) - no recompute at all: the
+    // recompute was 4.3 K of the 27.1 K cycles of a round (ab/q16/stamps_q16.py: phases 7 and 11 against 3 / 5 and the 3-layer kernel's 11)
+#ifdef NIC_Q16_D8
+    constexpr bool D8 = NIC_Q16_D8 != 0 && TRAIN;                     // experiment: derivatives as bytes (changes the mode's rounding points; off)
+#else
+    constexpr bool D8 = false;
+#endif
+    constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && NL == 5) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
 #ifdef NIC_Q16_RECOMP
     constexpr int RECOMP = NIC_Q16_RECOMP;
 #else
-    constexpr int RECOMP = (TRAIN && NL == 5) ? 2 : 0;
+    constexpr int RECOMP = 0;                                         // every derivative is kept since they are pinned (NIC_Q16_PIN); 2 = the recomputing form
 #endif
     __shared__ __attribute__((aligned(16))) __bf16 smemq[TRAIN ? S::TOTAL : S::OFF_IMG];
     lds_bf* const sm = (lds_bf*)smemq;
@@ -692,7 +740,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
         for (int it = it_begin; it < it_begin + it_len; ++it) {
             // ================= forward =================
-            bf16x8 dpk[NH + 1][2];                                            // GELU derivatives of every hidden activation, bf16, packed like the B fragments
+            bf16x8 dpk[D8 ? 1 : NH + 1][2];                                   // GELU derivatives of every hidden activation, bf16, packed like the B fragments
+            uint32_t dq[D8 ? NH + 1 : 1][4];                                  // .. or (D8) as bytes: dword t = the four values of row tile t
             float dz3[3];
             float kf[3];                                                      // G1 interpolation fractions of the sample
             {
@@ -780,12 +829,27 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 bf16x8 af[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    f32x4 a4[2], d4[2];
-                    gelu_and_grad4(z[2 * s], a4[0], d4[0]);
-                    gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                    af[s] = cvt_pair(a4[0], a4[1]);
-                    if (0 >= RECOMP) dpk[0][s] = cvt_pair(d4[0], d4[1]);
-                    NIC_Q16_SB;
+                    if constexpr (D8 && NIC_Q16_D8_ONE) {
+                        // one row tile at a time, packed at once (activation: two dwords, derivative: one): half the live values of the pairwise form
+                        u32x2 hp[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 a1, d1;
+                            gelu_and_grad4(z[2 * s + h], a1, d1);
+                            hp[h] = cvt_half(a1);
+                            if (0 >= RECOMP) dq[0][2 * s + h] = pack_d8(d1);
+                            NIC_Q16_SB;
+                        }
+                        af[s] = join_halves(hp[0], hp[1]);
+                    } else {
+                        f32x4 a4[2], d4[2];
+                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
+                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
+                        af[s] = cvt_pair(a4[0], a4[1]);
+                        if constexpr (D8) { if (0 >= RECOMP) { dq[0][2 * s] = pack_d8(d4[0]); dq[0][2 * s + 1] = pack_d8(d4[1]); } }
+                        else if (0 >= RECOMP) { dpk[0][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[0][s]); }
+                        NIC_Q16_SB;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
@@ -799,12 +863,26 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        f32x4 a4[2], d4[2];
-                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
-                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                        af[s] = cvt_pair(a4[0], a4[1]);
-                        if (k + 1 >= RECOMP) dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
-                        NIC_Q16_SB;
+                        if constexpr (D8 && NIC_Q16_D8_ONE) {
+                            u32x2 hp[2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                f32x4 a1, d1;
+                                gelu_and_grad4(z[2 * s + h], a1, d1);
+                                hp[h] = cvt_half(a1);
+                                if (k + 1 >= RECOMP) dq[k + 1][2 * s + h] = pack_d8(d1);
+                                NIC_Q16_SB;
+                            }
+                            af[s] = join_halves(hp[0], hp[1]);
+                        } else {
+                            f32x4 a4[2], d4[2];
+                            gelu_and_grad4(z[2 * s], a4[0], d4[0]);
+                            gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
+                            af[s] = cvt_pair(a4[0], a4[1]);
+                            if constexpr (D8) { if (k + 1 >= RECOMP) { dq[k + 1][2 * s] = pack_d8(d4[0]); dq[k + 1][2 * s + 1] = pack_d8(d4[1]); } }
+                            else if (k + 1 >= RECOMP) { dpk[k + 1][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[k + 1][s]); }
+                            NIC_Q16_SB;
+                        }
                     }
                 }
                 // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); its input fragments are the
@@ -880,7 +958,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const s16x4 a = tr4(&wo_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
-                        dzc[t] = mfma16_bf(join8(a, a), bf, f32x4(0.f)) * unpack4(dpk[NH][t >> 1], t & 1);
+                        const f32x4 dl = mfma16_bf(join8(a, a), bf, f32x4(0.f));
+                        if constexpr (D8) dzc[t] = dl * unpack_d8(dq[NH][t]);
+                        else dzc[t] = dl * unpack4(dpk[NH][t >> 1], t & 1);
                     }
                 }
             }
@@ -937,7 +1017,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 STAMP(4 + 2 * j);
                 if (k >= RECOMP) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+                    for (int t = 0; t < 4; ++t) {
+                        if constexpr (D8) dzc[t] = acc[t] * unpack_d8(dq[k][t]);
+                        else dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+                    }
+#ifdef NIC_Q16_SB2
+                    NIC_Q16_SB;
+#endif
                 } else {
                     // recompute the pre-activation whose GELU produced a_k: layer 1 (k = 0: X image, W1) or hidden layer k - 1 (A_{k-1} image)
                     const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
@@ -974,9 +1060,14 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         f32x4 a4[2], d4[2];
                         gelu_and_grad4(z[2 * s], a4[0], d4[0]);
                         gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                        const bf16x8 dp = cvt_pair(d4[0], d4[1]);           // rounded to bf16 like the kept ones
-                        dzc[2 * s] = acc[2 * s] * unpack4(dp, false);
-                        dzc[2 * s + 1] = acc[2 * s + 1] * unpack4(dp, true);
+                        if constexpr (D8) {                                 // rounded like the kept ones
+                            dzc[2 * s] = acc[2 * s] * unpack_d8(pack_d8(d4[0]));
+                            dzc[2 * s + 1] = acc[2 * s + 1] * unpack_d8(pack_d8(d4[1]));
+                        } else {
+                            const bf16x8 dp = cvt_pair(d4[0], d4[1]);
+                            dzc[2 * s] = acc[2 * s] * unpack4(dp, false);
+                            dzc[2 * s + 1] = acc[2 * s + 1] * unpack4(dp, true);
+                        }
                         NIC_Q16_SB;
                     }
                 }

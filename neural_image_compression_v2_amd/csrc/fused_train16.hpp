@@ -622,6 +622,10 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     //  spill, and the packed-fp32 GELU chains stop the matrix pipe rather than run beside it)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
+#ifdef NIC_T16_PIN
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
+#endif
                     NIC_T16_SB;
                     // ---------- layer 2
                     lds_cf* const b2_row = opaque(Bs + 4 * g);
@@ -642,6 +646,10 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
+#ifdef NIC_T16_PIN
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d2[t]));
+#endif
                 }
                 NIC_T16_SB;
                 // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
