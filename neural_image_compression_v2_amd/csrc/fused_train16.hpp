@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     //  spill, and the packed-fp32 GELU chains stop the matrix pipe rather than run beside it)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
-#ifdef NIC_T16_PIN
+#if defined(NIC_T16_PIN) && (NIC_T16_PIN & 1)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
 #endif
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
-#ifdef NIC_T16_PIN
+#if defined(NIC_T16_PIN) && (NIC_T16_PIN & 2)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d2[t]));
 #endif
