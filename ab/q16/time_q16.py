@@ -29,7 +29,7 @@ for name, nl, kw, gdt in [("split_nl3", 3, dict(split_bf16=True), torch.float32)
     flat = None
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for j in range(n + 5):
-        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL,
+        geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, W), num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL, use_tri_pe=os.environ.get("TRI", "1") != "0",
                                  noise_seed=7, noise_offset=j, flags=_lib.NIC_FLAG_ORIGINS_ALIGNED, **kw)
         o = fused.fused_forward_backward(geo, a, b, org, params, target, flat=flat, events=evs[j - 5] if j >= 5 else None)
         flat = o.flat

@@ -25,6 +25,9 @@
 #include "fused_kernel.hpp"
 
 
+#ifndef NIC_T16_PIN
+#define NIC_T16_PIN 4        // bit 0: pin d1, bit 1: pin d2, bit 2: pin d2 in the sinusoidal-PE layout only
+#endif
 namespace nic {
 
 struct Lds16 {
@@ -622,10 +625,13 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     //  spill, and the packed-fp32 GELU chains stop the matrix pipe rather than run beside it)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
-#if defined(NIC_T16_PIN) && (NIC_T16_PIN & 1)
+                    // (pinning the derivatives - fused_q16.hpp::pin - costs this kernel 3.7 % for d1 and 0.3 % for d2 with the triangular PE, where nothing
+                    //  spills: the compiler's sinking of their last steps spreads vector work into the backward pass.  The sinusoidal-PE layout spilled
+                    //  6 - 9 registers: pinning d2 there removes them)
+                    if (NIC_T16_PIN & 1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
-#endif
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
+                    }
                     NIC_T16_SB;
                     // ---------- layer 2
                     lds_cf* const b2_row = opaque(Bs + 4 * g);
@@ -646,10 +652,10 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a2[t], d2[t]);
-#if defined(NIC_T16_PIN) && (NIC_T16_PIN & 2)
+                    if ((NIC_T16_PIN & 2) || ((NIC_T16_PIN & 4) && L::PE == NIC_PE_SINUSOIDAL)) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d2[t]));
-#endif
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d2[t]));
+                    }
                 }
                 NIC_T16_SB;
                 // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
