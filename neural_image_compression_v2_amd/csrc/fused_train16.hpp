@@ -26,7 +26,7 @@
 
 
 #ifndef NIC_T16_PIN
-#define NIC_T16_PIN 4        // bit 0: pin d1, bit 1: pin d2, bit 2: pin d2 in the sinusoidal-PE layout only
+#define NIC_T16_PIN 0        // bit 0: pin d1, bit 1: pin d2, bit 2: pin d2 in the sinusoidal-PE layout only (all measured: no gain in this kernel, see below)
 #endif
 namespace nic {
 
@@ -626,8 +626,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a1[t], d1[t]);
                     // (pinning the derivatives - fused_q16.hpp::pin - costs this kernel 3.7 % for d1 and 0.3 % for d2 with the triangular PE, where nothing
-                    //  spills: the compiler's sinking of their last steps spreads vector work into the backward pass.  The sinusoidal-PE layout spilled
-                    //  6 - 9 registers: pinning d2 there removes them)
+                    //  spills: the compiler's sinking of their last steps spreads vector work into the backward pass.  The sinusoidal-PE layout spills
+                    //  6 - 9 registers; pinning d2 there removes them and changes nothing: 2.236 against 2.230 ms)
                     if (NIC_T16_PIN & 1) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
