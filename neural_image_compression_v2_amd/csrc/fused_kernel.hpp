@@ -1064,7 +1064,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
         // training: the 2D kernels have the registers for a cell's raw values since the build keeps MFMA results out of the
         // accumulator file where vector code consumes them: G0 (24 values) -1.8 % split, -1 % fp32; G0 + G1 (48) another -1.8 % in the
         // split kernel although 9 values spill (the fp32 kernel with both: the compiler gives up); 3D: none
-        constexpr int HOIST_TRAIN = NIC_HOIST_TRAIN >= 0 ? NIC_HOIST_TRAIN : (L::DIM == 2 ? (SPLIT ? NIC_HOIST_SPLIT : 1) : NIC_HOIST_3D);
+        constexpr int HOIST_TRAIN = NIC_HOIST_TRAIN >= 0 ? NIC_HOIST_TRAIN : (L::DIM == 2 ? (SPLIT ? NIC_HOIST_SPLIT : 3) : NIC_HOIST_3D);   // 2D fp32: both grids since the derivatives are pinned (no spill; 4.404 -> 4.380 ms)
         constexpr bool HG0 = SRC == SRC_ENCODE && ((TRAIN ? HOIST_TRAIN : HOIST_INFER) & 1) != 0;
         constexpr bool HG1 = SRC == SRC_ENCODE && ((TRAIN ? HOIST_TRAIN : HOIST_INFER) & 2) != 0;
         CellRaw<L> raw;

@@ -522,7 +522,7 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 }
 
 #ifndef NIC_Q16_PIN
-#define NIC_Q16_PIN 2        // pin the derivative fragments: 1 everywhere, 2 with 5 layers only (measured, interleaved A/B: pinning costs the 3-layer kernels 0.8 % in 2D, 2 % with method 4)
+#define NIC_Q16_PIN 2        // pin the derivative fragments: 1 everywhere, 2 with 5 layers and for method 3 (measured, interleaved A/B: pinning costs the 3-layer kernels 0.8 % in 2D, 2 % with method 4)
 #endif
 #ifndef NIC_Q16_D8_ONE
 #define NIC_Q16_D8_ONE 1
@@ -558,7 +558,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #else
     // measured (4K / 128^3 launches, interleaved A/B on one box, hoist 0 / 1 / 3): 2D NL 3: 1.51 / 1.49 / 1.45 ms, NL 5: 3.65 / 3.77 / 4.25 (spills);
     // method 4: 0.616 / 0.558 / 0.543 ms; method 3: 0.525 / 0.539 / 0.601 (spills)
-    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? (Q::NG0 == 1 ? 3 : 0) : (Q::NG0 == 1 ? 3 : 0));
+    // (second half of round 3: with the derivatives pinned method 3 keeps both grids' raw values too - 5 spilled registers instead of the 48 that made
+    //  hoisting lose: 0.552 -> 0.517 ms at 128^3, 0.585 -> 0.52 with 16-bit grids; its 5-layer form still spills with them: not hoisted there)
+    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? 3 : (Q::NG0 == 1 ? 3 : 0));
 #endif
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
     // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per layer), except - 5 layers - those of the first RECOMP
@@ -573,7 +575,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #else
     constexpr bool D8 = false;
 #endif
-    constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && NL == 5) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
+    constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && (NL == 5 || Q::NG0 == 2)) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
 #ifdef NIC_Q16_RECOMP
     constexpr int RECOMP = NIC_Q16_RECOMP;
 #else
