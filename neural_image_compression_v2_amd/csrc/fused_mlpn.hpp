@@ -14,6 +14,9 @@
 #pragma once
 #include "fused_train16.hpp"
 
+#ifndef NIC_MLPN_PIN
+#define NIC_MLPN_PIN 1        // pin the GELU derivatives (fused_q16.hpp::pin): 430 -> 343 registers with 5 layers, 4K launch 4.98 -> 4.86 ms
+#endif
 namespace nic {
 
 template <int NL>
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a[0][t], d[0][t]);
-#ifdef NIC_MLPN_PIN
+#if NIC_MLPN_PIN
 #pragma unroll
                     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[0][t]));
 #endif
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a[k + 1][t], d[k + 1][t]);
-#ifdef NIC_MLPN_PIN
+#if NIC_MLPN_PIN
 #pragma unroll
                     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[k + 1][t]));
 #endif
