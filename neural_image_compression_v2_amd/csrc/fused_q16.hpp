@@ -230,9 +230,9 @@ __device__ __forceinline__ f32x4 unpack_d8(uint32_t w) {
     return r;
 }
 // acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
-template <int NT, bool ZERO = false, class LoadA>
+template <int NT, bool ZERO = false, int PFQ = NIC_T16_PF, class LoadA>
 __device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, LoadA&& load_a) {
-    constexpr int PF = NIC_T16_PF < NT ? NIC_T16_PF : NT;
+    constexpr int PF = PFQ < NT ? PFQ : NT;
     bf16x8 af[PF];
 #pragma unroll
     for (int t = 0; t < PF; ++t) af[t] = load_a(t);
@@ -549,6 +549,12 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     constexpr bool HALF = I::HALF;
     constexpr int LD1 = S::LD1, LDH = S::LDH, LDZ = S::LDZ, LDX = S::LDX;
     static_assert(NL == 3 || NL == 5, "3 or 5 Linear layers");
+    // A fragments of a k-step fetched this many row tiles ahead: all four with 3 layers (1.460 -> 1.435 ms at 4K), two with 5 (four: 2.40 -> 2.45)
+#ifdef NIC_Q16_PF
+    constexpr int KPF = NIC_Q16_PF;
+#else
+    constexpr int KPF = NL == 3 ? 4 : 2;
+#endif
     constexpr bool TRAIN = MODE != MODE_INFER;                  // MODE_INFER: the forward pass alone (decode_image for the layouts only these kernels serve)
     // raw grid values gathered once per macro-tile (every sample a lane handles there lies in the same G0 / G1 cell) and kept in registers where
     // the budget of two waves per SIMD allows, otherwise re-fetched at the end of every round for the next one (L1 / L2 hits; dead through
@@ -814,7 +820,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6], xs[8 * s + 7]};
                         const bf16x8 bf = cvt8(xv);
                         if (TRAIN) st_frag(&x_st[32 * s], bf);
-                        kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
+                        kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
                     }
                     if constexpr (HALF) {   // slots 8 KF .. 8 KF + 3: compact columns 32 KF + 4 g + j
                         lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
@@ -823,7 +829,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         const bf16x8 bf = cvt8(xv);
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf);
                         if (TRAIN) *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
-                        kstep_b<4>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                        kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
                     }
                 }
                 // ---------- hidden layers: the B fragments of layer k + 1 are the image A_k of its weight gradient
@@ -861,7 +867,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         if (TRAIN) st_frag(&a_st[32 * s], af[s]);
-                        kstep_b<4>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
+                        kstep_b<4, false, KPF>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -987,8 +993,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                             const int co = 32 * (t >> 1) + 4 * (t & 1);
                             return join8(tr4(&wh_tr[32 * s * LDH + co]), tr4(&wh_tr[(32 * s + 16) * LDH + co]));
                         };
-                        if (s == 0) kstep_b<4, true>(acc, bf, la);
-                        else kstep_b<4>(acc, bf, la);
+                        if (s == 0) kstep_b<4, true, KPF>(acc, bf, la);
+                        else kstep_b<4, false, KPF>(acc, bf, la);
                     }
                     wave_lds_fence();
                     {   // db[pos = lane] += sum_n dZ[pos][n]: 4x4x4 MFMAs against a block of ones
@@ -1040,13 +1046,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                         for (int s = 0; s < KF; ++s) {
                             const bf16x8 bf = ld_frag(&x_ld[32 * s]);
-                            kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
+                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
                         }
                         if constexpr (HALF) {
                             lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
                             lds_cbf* const x_ld2 = opaque((lds_cbf*)(imgw + n16 * LDX + 32 * KF + 4 * g));
                             const bf16x8 bf = half_frag(*reinterpret_cast<lds_cs16x4*>(x_ld2));
-                            kstep_b<4>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
                         }
                     } else {
                         lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));
@@ -1054,7 +1060,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
                             const bf16x8 bf = ld_frag(&a_ld[32 * s]);
-                            kstep_b<4>(z, bf, [&](int t) { return ld_frag(&w_row[S::OFF_WH + (k - 1) * S::WSZ + 16 * t * LDH + 32 * s]); });
+                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w_row[S::OFF_WH + (k - 1) * S::WSZ + 16 * t * LDH + 32 * s]); });
                         }
                     }
 #pragma unroll
@@ -1088,7 +1094,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
                     st_frag(&dz_st[32 * s], bf);
-                    kstep_b<NDX>(dxacc, bf, [&](int t) {
+                    kstep_b<NDX, false, KPF>(dxacc, bf, [&](int t) {
                         const int co = 32 * (t >> 1) + 4 * (t & 1);
                         return join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
                     });
