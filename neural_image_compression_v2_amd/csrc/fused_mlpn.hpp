@@ -258,12 +258,24 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
                             *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
                             *reinterpret_cast<lds_s16x4*>(x_st2 + XLO) = s16x4{bl[0], bl[1], bl[2], bl[3]};
                         }
+#if NIC_T16_HALF16
+                        {   // v_mfma_f32_16x16x16_bf16 on the compact half k-step (fused_train16.hpp)
+                            const s16x8 qh = __builtin_bit_cast(s16x8, bf.hi), ql = __builtin_bit_cast(s16x8, bf.lo);
+                            const Half2 bq = {s16x4{qh[0], qh[1], qh[2], qh[3]}, s16x4{ql[0], ql[1], ql[2], ql[3]}};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const Half2 aq = {*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD]), *reinterpret_cast<lds_cs16x4*>(&w1_row2[S::LO + 16 * t * LD])};
+                                z[t] = mfma16h_split(aq, bq, z[t]);
+                            }
+                        }
+#else
                         kstep16<4>(z, bf, [&](int t) {
                             Frag2 af;
                             af.hi = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD]));
                             af.lo = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[S::LO + 16 * t * LD]));
                             return af;
                         });
+#endif
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) gelu_and_grad4(z[t], a[0][t], d[0][t]);

@@ -25,6 +25,9 @@
 #include "fused_kernel.hpp"
 
 
+#ifndef NIC_T16_HALF16
+#define NIC_T16_HALF16 1
+#endif
 #ifndef NIC_T16_PIN
 #define NIC_T16_PIN 0        // bit 0: pin d1, bit 1: pin d2, bit 2: pin d2 in the sinusoidal-PE layout only (all measured: no gain in this kernel, see below)
 #endif
@@ -82,6 +85,17 @@ __device__ __forceinline__ void st_frag(lds_bf* p, const bf16x8& f) { *reinterpr
 __device__ __forceinline__ bf16x8 half_frag(s16x4 a) {               // k = 0..3 real, 4..7 zero
     const s16x8 v = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
     return __builtin_bit_cast(bf16x8, v);
+}
+// The compact half k-step (input columns 64 .. 79: four slots per lane quarter) is exactly the operand layout of v_mfma_f32_16x16x16_bf16 (quarter g holds
+// k = 4g .. 4g+3): no zero-padded 8-element fragments to assemble (4 register moves per fragment: ~ 40 per round in the split kernel) and half the pipe time.
+struct Half2 {
+    s16x4 hi, lo;
+};
+__device__ __forceinline__ f32x4 mfma16h_bf(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16h_split(const Half2& a, const Half2& b, f32x4 c) {
+    c = mfma16h_bf(a.lo, b.hi, c);
+    c = mfma16h_bf(a.hi, b.lo, c);
+    return mfma16h_bf(a.hi, b.hi, c);
 }
 __device__ __forceinline__ f32x4 mfma16_split(const Frag2& a, const Frag2& b, f32x4 c) {
     c = mfma16_bf(a.lo, b.hi, c);
@@ -614,12 +628,21 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf.hi), bl = __builtin_bit_cast(s16x8, bf.lo);
                         *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
                         *reinterpret_cast<lds_s16x4*>(x_st2 + S::XLO) = s16x4{bl[0], bl[1], bl[2], bl[3]};
+#if NIC_T16_HALF16
+                        const Half2 bq = {s16x4{bh[0], bh[1], bh[2], bh[3]}, s16x4{bl[0], bl[1], bl[2], bl[3]}};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const Half2 a = {*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]), *reinterpret_cast<lds_cs16x4*>(&w1_row2[S::W1LO + 16 * t * LD1])};
+                            z[t] = mfma16h_split(a, bq, z[t]);
+                        }
+#else
                         kstep16<4>(z, bf, [&](int t) {
                             Frag2 a;
                             a.hi = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]));
                             a.lo = half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[S::W1LO + 16 * t * LD1]));
                             return a;
                         });
+#endif
                     }
                     // (tile-outer order - the GELU of row tile t beside the MFMAs of tile t + 1 - measured 3.5 % slower: 8 more registers
                     //  spill, and the packed-fp32 GELU chains stop the matrix pipe rather than run beside it)
