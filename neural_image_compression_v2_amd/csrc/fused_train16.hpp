@@ -25,6 +25,9 @@
 #include "fused_kernel.hpp"
 
 
+#ifndef NIC_T16_NOISE_VEC
+#define NIC_T16_NOISE_VEC 0        // measured: the copy goes, the launch gets 2.8 % slower (2.137 -> 2.198 ms): off
+#endif
 #ifndef NIC_T16_HALF16
 #define NIC_T16_HALF16 1
 #endif
@@ -235,6 +238,33 @@ __host__ __device__ constexpr int xs_of_slot(int s) { return s < 15 ? s : s - 1;
 // exactly generator block g of its sample - fields 0..11 the G0 channels, 12..14 the G1 channels, 15..17 the PE rows, 18 the LOD.
 template <class L>
 __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int g, float (&xs)[20]) {
+#if NIC_T16_NOISE_VEC
+    // The noise of the 19 real slots as a vector of its own, added once behind the mode switch: with in-place adds inside the three-way branch the
+    // slot values met in a phi and the generator path began with a copy of all of them (16 v_mov_b64 per round in the ISA).
+    float nv[19];
+    if (ns.mode == NIC_NOISE_TENSOR) {
+        const float* row = ns.tensor + n_local * L::CIN;
+#pragma unroll
+        for (int s = 0; s < 20; ++s) {
+            if (s == 15) continue;
+            const int ch0 = slot16_channel(s, 0);
+            if (s == 19) { nv[18] = g == 0 ? row[72] : 0.f; continue; }
+            const int stride = slot16_channel(s, 1) - ch0;        // the channel is affine in g for every other real slot
+            nv[xs_of_slot(s)] = row[ch0 + stride * g];
+        }
+    } else if (ns.mode == NIC_NOISE_KERNEL) {
+        const U4 b = noise_block(ns, sample_global, g);
+#pragma unroll
+        for (int f = 0; f < 18; ++f) nv[f] = noise_field(ns, b, f);
+        const float nl = noise_field(ns, b, 18);
+        nv[18] = g == 0 ? nl : 0.f;
+    } else {
+#pragma unroll
+        for (int f = 0; f < 19; ++f) nv[f] = 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 19; ++f) xs[f] += nv[f];
+#else
     if (ns.mode == NIC_NOISE_NONE) return;
     if (ns.mode == NIC_NOISE_TENSOR) {
         const float* row = ns.tensor + n_local * L::CIN;
@@ -253,6 +283,7 @@ __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_
     for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
     const float nl = noise_field(ns, b, 18);
     xs[18] += g == 0 ? nl : 0.f;
+#endif
 }
 
 // G1 sums of the lanes whose G0 cells share a G1 cell are added across lanes before the flush (see combine_g1_lanes)
