@@ -796,14 +796,22 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     lds_cbf* const w3_tr = opaque((lds_cbf*)(sm + S::OFF_W3 + q4 * LD3 + 8 * p4));
                     const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
                     const Frag2 bf = split8(dzv);
+                    const s16x8 b3h = __builtin_bit_cast(s16x8, bf.hi), b3l = __builtin_bit_cast(s16x8, bf.lo);
+                    const Half2 bq3 = {s16x4{b3h[0], b3h[1], b3h[2], b3h[3]}, s16x4{b3l[0], b3l[1], b3l[2], b3l[3]}};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const s16x4 ahh = tr4(&w3_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
                         const s16x4 all = tr4(&w3_tr[S::W3LO + 32 * (t >> 1) + 4 * (t & 1)]);
+#if NIC_T16_HALF16
+                        // k = c < 4 lives in quarter 0 of either MFMA shape: the 16x16x16 one takes the transposed read as it is (no doubled fragment)
+                        const Half2 aq = {ahh, all};
+                        dz2[t] = mfma16h_split(aq, bq3, f32x4(0.f)) * d2[t];
+#else
                         Frag2 af;
                         af.hi = join8(ahh, ahh);
                         af.lo = join8(all, all);
                         dz2[t] = mfma16_split(af, bf, f32x4(0.f)) * d2[t];
+#endif
                     }
                 }
                 STAMP(2);    // dZ3 image, dW3, dA2
