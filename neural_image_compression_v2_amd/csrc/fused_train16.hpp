@@ -25,6 +25,9 @@
 #include "fused_kernel.hpp"
 
 
+#ifndef NIC_T16_NOISE_ORDER
+#define NIC_T16_NOISE_ORDER 0        // generator branch first: more copies, not fewer (ISA): off
+#endif
 #ifndef NIC_T16_NOISE_VEC
 #define NIC_T16_NOISE_VEC 0        // measured: the copy goes, the launch gets 2.8 % slower (2.137 -> 2.198 ms): off
 #endif
@@ -265,8 +268,21 @@ __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_
 #pragma unroll
     for (int f = 0; f < 19; ++f) xs[f] += nv[f];
 #else
+#if NIC_T16_NOISE_ORDER
+    if (ns.mode == NIC_NOISE_KERNEL) {
+        const U4 b = noise_block(ns, sample_global, g);
+#pragma unroll
+        for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
+        const float nl = noise_field(ns, b, 18);
+        xs[18] += g == 0 ? nl : 0.f;
+        return;
+    }
+    if (ns.mode != NIC_NOISE_TENSOR) return;
+    {
+#else
     if (ns.mode == NIC_NOISE_NONE) return;
     if (ns.mode == NIC_NOISE_TENSOR) {
+#endif
         const float* row = ns.tensor + n_local * L::CIN;
 #pragma unroll
         for (int s = 0; s < 20; ++s) {
@@ -278,11 +294,13 @@ __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_
         }
         return;
     }
+#if !NIC_T16_NOISE_ORDER
     const U4 b = noise_block(ns, sample_global, g);
 #pragma unroll
     for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
     const float nl = noise_field(ns, b, 18);
     xs[18] += g == 0 ? nl : 0.f;
+#endif
 #endif
 }
 
