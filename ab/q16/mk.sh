@@ -7,7 +7,7 @@ C=neural_image_compression_v2_amd/csrc
 python -m neural_image_compression_v2_amd._build >/dev/null
 T=/tmp/abq_$NAME; mkdir -p $T
 for m in 1 2 3 4; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function "$@" -c $C/fused_q$m.hip -o $T/fused_q$m.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize -Wno-unused-function "$@" -c $C/fused_q$m.hip -o $T/fused_q$m.o &
 done
 wait
 B=$C/build

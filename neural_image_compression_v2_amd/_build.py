@@ -54,6 +54,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(job):
         s, o = job
         extra = ["-ffp-contract=off"] if os.path.basename(s) == "simple_kernels.hip" else []   # op-by-op rounding like eager torch
+        # the plain-bf16 kernels without SLP vectorisation (the guide's anti-lever: adjacent scalar f32 operations packed into v_pk_* beside MFMAs):
+        # 4K launch 1.420 -> 1.401 ms, 128^3 method 3 0.483 -> 0.461, method 4 0.426 -> 0.417 (interleaved A/B, identical results); the split and fp32
+        # kernels do not move (or lose 1 %): they keep the default
+        if os.path.basename(s).startswith("fused_q"):
+            extra.append("-fno-slp-vectorize")
         cmd = [hipcc, *FLAGS, *extra, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
