@@ -415,6 +415,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     // (8 groups in segment 0 - a macro-tile's groups in two workgroups, two flushes: the reference's 3D sweep shape 0.368 -> 0.332 ms with
     //  method 4; method 3, twice the sums per lane, lost 5 % until its flush pre-added neighbouring sums and gains 6 % since)
     balance_units(p, 1, wpw, (t16 || q16) && two_seg, !t16 && !q16 && !mlpn && two_seg, NIC_RG_SEG0, q16 ? NIC_Q16_RG0 : 0);
+    p.preadd_y = p.n_tiles <= (int64_t)4 * wpw * cu_count() ? 1 : 0;
     const int64_t units0 = p.seg_split << p.rg0_log2, units1 = (p.n_tiles - p.seg_split) << p.rg_log2;
     const int64_t units_max = units0 > units1 ? units0 : units1;
     if (units_max >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;                    // the kernels count work units in 32 bits

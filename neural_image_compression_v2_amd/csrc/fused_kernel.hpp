@@ -71,6 +71,9 @@ enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2, MODE_TRAIN_IMG = 3
 // spilled registers method 3 130 -> 16 (split) / 115 -> 1 (fp32), method 4 112 -> 4, 2D 20 -> 0; 128^3 split steps 1.42 -> 0.94 ms (method 3), 1.04 -> 0.81
 // (method 4); the fp32 4K launch 4.58 -> 4.40 ms.  (fused_train16, which does not spill, LOSES 3.9 % with the same pin: there the sinking spreads vector
 // work into the backward pass.)
+#ifndef NIC_PREADD_Y_SMALL
+#define NIC_PREADD_Y_SMALL 1      // 1: the y pre-add only where FusedParams.preadd_y says so (small launches); 0: always (round 2's behaviour)
+#endif
 #ifndef NIC_FK_PIN
 #define NIC_FK_PIN 1
 #endif
@@ -120,6 +123,10 @@ struct FusedParams {
     // hipGraph-captured training loops (nic_fused_forward_backward_img_dev): the step number lives in DEVICE memory and is added to the
     // noise offset at kernel start, so one captured launch serves every step (fused_train16 / fused_q16 kernels; null everywhere else)
     const int64_t* step_dev;
+    // two-waves-per-SIMD kernels: pre-add the G0 sums along y across the waves of a workgroup before the flush (two barriers + an LDS exchange per
+    // macro-tile: halves the atomics - what small launches are bound by - and costs a launch that fills the chip many times over ~ 0.9 %): set by the host
+    // for launches of at most 4 macro-tiles per wave of the chip
+    int preadd_y;
 };
 // the launch's noise source with the device-side step added to its offset (uniform: scalar registers)
 __device__ __forceinline__ NoiseSrc noise_with_step(const NoiseSrc& base, const int64_t* step_dev) {

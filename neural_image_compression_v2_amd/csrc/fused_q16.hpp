@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             }
             constexpr bool SHARE_XY = !Q::TETRA;                            // method 4's tetrahedra share no corner along x or y
             if (SHARE_XY && NIC_Q16_PREADD && flush && !packed) preadd_x_q<NG0T>(dxacc, blk_off0, ln);
-            if (SHARE_XY && NIC_Q16_PREADD >= 2 && rg == 0 && !packed) {    // segment-uniform
+            if (SHARE_XY && NIC_Q16_PREADD >= 2 && rg == 0 && !packed && (p.preadd_y || !NIC_PREADD_Y_SMALL)) {    // segment-uniform
                 static_assert((I::NG0V + 1) * 64 * 2 <= S::SCRATCH, "pre-add scratch");
                 preadd_y_q<NG0T>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, REGION, barrier);
             }

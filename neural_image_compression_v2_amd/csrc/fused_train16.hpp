@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             flush = false;                                                  // timing ablation only
 #endif
             if (flush && NIC_T16_PREADD) preadd_x16(dxacc, blk_off0, ln);
-            if (NIC_T16_PREADD >= 2 && rg == 0) {                           // segment-uniform
+            if (NIC_T16_PREADD >= 2 && rg == 0 && (p.preadd_y || !NIC_PREADD_Y_SMALL)) {      // segment-uniform
                 static_assert(13 * 64 <= S::SPW / 2, "pre-add scratch");
                 preadd_y16<8>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, S::SPW / 2, [&]() { half_barrier(bar_cnt, bar_target, lane); });
             }
