@@ -521,6 +521,9 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
     barrier();
 }
 
+#ifndef NIC_RQ_SLICES
+#define NIC_RQ_SLICES 8        // record slices summed in parallel by reduce_q16_kernel (32 outputs x slices threads per block)
+#endif
 #ifndef NIC_Q16_HALF16
 #define NIC_Q16_HALF16 0
 #endif
@@ -1304,13 +1307,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 // Fixed-order reduction of the records of fused_q16_kernel.  Output index space, layer by layer:
 // W1 [64][Cin] | b1 [64] | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
 template <class Q, int NL>
-__global__ void __launch_bounds__(256) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
     using S = LdsQ<Q, NL>;
     using I = QInfo<Q>;
     constexpr int NH = S::NH, KF = I::KF;
     constexpr int N_W1 = kH * Q::CIN, N_HID = kH * kH + kH;
     constexpr int N_OUT = N_W1 + kH + NH * N_HID + 3 * kH + 3 + 1;
-    __shared__ float red[8][32];
+    __shared__ float red[NIC_RQ_SLICES][32];
     const int slice = threadIdx.x >> 5;
     const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
     const bool live = gid < N_OUT;
@@ -1369,7 +1372,7 @@ __global__ void __launch_bounds__(256) reduce_q16_kernel(const float* partials, 
         }
     }
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
-    const int per = (n_rec + 7) >> 3;
+    const int per = (n_rec + NIC_RQ_SLICES - 1) / NIC_RQ_SLICES;
     const int w_lo = slice * per, w_hi = (w_lo + per < n_rec) ? w_lo + per : n_rec;
     if (live && dst != nullptr) {
         for (int k = 0; k < nsrc; ++k) {
@@ -1387,7 +1390,7 @@ __global__ void __launch_bounds__(256) reduce_q16_kernel(const float* partials, 
     if (slice != 0 || !live || dst == nullptr) return;
     float acc = red[0][threadIdx.x];
 #pragma unroll
-    for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
+    for (int sl = 1; sl < NIC_RQ_SLICES; ++sl) acc += red[sl][threadIdx.x];
     *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
 }
 
