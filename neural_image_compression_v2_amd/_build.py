@@ -57,7 +57,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # the plain-bf16 kernels without SLP vectorisation (the guide's anti-lever: adjacent scalar f32 operations packed into v_pk_* beside MFMAs):
         # 4K launch 1.420 -> 1.401 ms, 128^3 method 3 0.483 -> 0.461, method 4 0.426 -> 0.417 (interleaved A/B, identical results); the split and fp32
         # kernels do not move (or lose 1 %): they keep the default
-        if os.path.basename(s).startswith("fused_q"):
+        # (fused_t16: 2.122 -> 2.104 ms on the final kernel; it did not move before the 16x16x16 products went in)
+        if os.path.basename(s).startswith("fused_q") or os.path.basename(s) == "fused_t16.hip":
             extra.append("-fno-slp-vectorize")
         cmd = [hipcc, *FLAGS, *extra, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
