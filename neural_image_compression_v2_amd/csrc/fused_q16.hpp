@@ -525,7 +525,7 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #define NIC_RQ_SLICES 8        // record slices summed in parallel by reduce_q16_kernel (32 outputs x slices threads per block)
 #endif
 #ifndef NIC_Q16_HALF16
-#define NIC_Q16_HALF16 0
+#define NIC_Q16_HALF16 2        // 1: always, 2: with 5 layers
 #endif
 #ifndef NIC_Q16_PIN
 #define NIC_Q16_PIN 2        // pin the derivative fragments: 1 everywhere, 2 with 5 layers and for method 3 (measured, interleaved A/B: pinning costs the 3-layer kernels 0.8 % in 2D, 2 % with method 4)
@@ -835,15 +835,15 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         const bf16x8 bf = cvt8(xv);
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf);
                         if (TRAIN) *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
-#if NIC_Q16_HALF16
-                        // the compact half k-step IS the operand layout of v_mfma_f32_16x16x16_bf16 (fused_train16.hpp): no zero-padded fragments
-                        // (measured here: 1.431 -> 1.451 ms with 3 layers, nothing with 5 or method 4 - off; the split kernel gains 0.8 %)
-                        const s16x4 bq = {bh[0], bh[1], bh[2], bh[3]};
+                        if constexpr (NIC_Q16_HALF16 == 1 || (NIC_Q16_HALF16 == 2 && NL == 5)) {
+                            // the compact half k-step IS the operand layout of v_mfma_f32_16x16x16_bf16 (fused_train16.hpp): no zero-padded fragments
+                            // (measured: 5 layers 2.365 -> 2.348 ms; 3 layers and method 4 unchanged - with SLP vectorisation still on it LOST 1.4 % there)
+                            const s16x4 bq = {bh[0], bh[1], bh[2], bh[3]};
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) z[t] = mfma16h_bf(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]), bq, z[t]);
-#else
-                        kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
-#endif
+                            for (int t = 0; t < 4; ++t) z[t] = mfma16h_bf(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]), bq, z[t]);
+                        } else {
+                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                        }
                     }
                 }
                 // ---------- hidden layers: the B fragments of layer k + 1 are the image A_k of its weight gradient
