@@ -512,6 +512,9 @@ int nic_fused_forward_u8(const nic_path_desc* d, const uint8_t* g0_u8, const uin
                          float* y, uint8_t* y_u8, void* stream) {
     const int layout = pick_layout(d);
     if (layout < 0) return layout;
+    // the stored-codec kernels are the 32-sample / depth-generic families, built for C = 12, P = 6 (with NIC_FLAG_BF16 pick_layout also answers for
+    // the plain-bf16 kernels' other widths, which have no uint8 grid kind): the caller decodes through fp_load + the layer-wise route instead
+    if (!cp_default(d)) return NIC_E_UNSUPPORTED;
     if (mlp && depth_unsupported(mlp)) return NIC_E_UNSUPPORTED;      // the fused kernels exist for 3 and 5 Linear layers
     int rc = check_geometry(d);
     if (rc) return rc;

@@ -249,7 +249,9 @@ typedef __attribute__((address_space(3))) const __bf16 lds_cbf;
 typedef __attribute__((address_space(3))) const s16x4 lds_cs16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ lds_cbf* opaque(lds_cbf* p) {
+#ifndef NIC_NO_OPAQUE_PTR
     asm volatile("" : "+v"(p));
+#endif
     return p;
 }
 __device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -353,7 +355,9 @@ typedef __attribute__((address_space(3))) float lds_f;            // 32-bit LDS 
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 __device__ __forceinline__ lds_f* opaque(lds_f* p) {
+#ifndef NIC_NO_OPAQUE_PTR
     asm volatile("" : "+v"(p));
+#endif
     return p;
 }
 __device__ __forceinline__ f32x4 ld4(lds_cf* p) { return *reinterpret_cast<lds_cf4*>(p); }

@@ -174,14 +174,20 @@ struct LdsQ {
     static constexpr int REC = REC_WAVE + 8 * WTAIL;
 };
 
-// 8 fp32 values -> one bf16 fragment (round to nearest even: v_cvt_pk_bf16_f32)
+// two fp32 values -> a bf16 pair (round to nearest even: v_cvt_pk_bf16_f32).  (Measured and dropped: the rounding in integer arithmetic - bits + 0x8000 per
+// value, one v_perm_b32 per pair - is 3 instructions for 1 and cost the 5-layer 4K launch +5.8 %: this kernel is bound by instruction ISSUE, ~ 4 cycles of
+// the SIMD per vector instruction of any kind.  __builtin_amdgcn_perm on the two lanes of a packed-fp32 result is also MISCOMPILED by ROCm 7.2 - both
+// operands become the low lane.)
+__device__ __forceinline__ uint32_t pk16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ __bf16 bf16_1(float v) { return (__bf16)v; }
+// 8 fp32 values -> one bf16 fragment
 __device__ __forceinline__ bf16x8 cvt8(const float (&x)[8]) {
     u32x4 hp;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x2 v = {x[2 * i], x[2 * i + 1]};
-        hp[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    }
+    for (int i = 0; i < 4; ++i) hp[i] = pk16(x[2 * i], x[2 * i + 1]);
     return __builtin_bit_cast(bf16x8, hp);
 }
 __device__ __forceinline__ bf16x8 cvt_pair(const f32x4& a, const f32x4& b) {        // registers of row tiles 2s, 2s + 1 = k-step s
@@ -197,13 +203,6 @@ __device__ __forceinline__ void pin(bf16x8& f) {
     asm volatile("" : "+v"(t));
     f = __builtin_bit_cast(bf16x8, t);
 }
-// one row tile's four values -> half a fragment (two dwords), and the fragment of two halves
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2 cvt_half(const f32x4& a) {
-    const f32x2 v0 = {a[0], a[1]}, v1 = {a[2], a[3]};
-    return u32x2{__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2)), __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2))};
-}
-__device__ __forceinline__ bf16x8 join_halves(const u32x2& lo, const u32x2& hi) { return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]}); }
 // the fp32 values of a packed fragment: elements 0..3 (lo = false) or 4..7 (lo = true)
 __device__ __forceinline__ f32x4 unpack4(const bf16x8& f, bool hi4) {
     const u32x4 w = __builtin_bit_cast(u32x4, f);
@@ -211,24 +210,21 @@ __device__ __forceinline__ f32x4 unpack4(const bf16x8& f, bool hi4) {
     return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u), __builtin_bit_cast(float, b << 16),
                  __builtin_bit_cast(float, b & 0xFFFF0000u)};
 }
-// GELU derivatives as 8-bit fixed point (5-layer decoders: four hidden layers' derivatives in the 16 registers two layers take as bf16): d in
-// [-0.129, 1.129] -> q = rne((d + 0.13) * 255 / 1.26) in 0 .. 255 (v_cvt_pk_u8_f32 rounds to nearest even and saturates: ab/micro/cvt_u8_probe.hip),
-// d' = q * (1.26 / 255) - 0.13: |d' - d| <= 0.0025 (bf16 keeps d to 0.002 near 1).  Restated by oracle/nic_oracle.py::quantize_gelu_grad_u8.
-__device__ __forceinline__ uint32_t pack_d8(const f32x4& d) {
-    uint32_t w = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d[i], 202.38095092773438f, 26.309524536132812f), (uint32_t)i, w);
-    // materialise the bytes HERE: left alone the compiler sinks the tail of the derivative (z phi(z) + Phi(z), the scaling, the packing) down to its
-    // use in the backward pass and keeps three fp32 intermediates per value alive across the whole round instead of one byte (130 spilled registers)
-    asm volatile("" : "+v"(w));
-    return w;
+// GELU + derivative of one row tile (four values per lane) in the form the plain 16-bit modes use (nic_device.hpp::gelu_sig4); 0 = the exact-erf form
+#ifndef NIC_Q16_GELU
+#define NIC_Q16_GELU 2
+#endif
+__device__ __forceinline__ void gelu_q(const f32x4& z, f32x4& a, f32x4& d) {
+    if constexpr (NIC_Q16_GELU == 0) gelu_and_grad4(z, a, d);
+    else gelu_sig4<NIC_Q16_GELU>(z, a, d);
 }
-__device__ __forceinline__ f32x4 unpack_d8(uint32_t w) {
-    f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fmaf((float)((w >> (8 * i)) & 255u), 0.004941176623106003f, -0.12999999523162842f);   // v_cvt_f32_ubyteN + fma
-    return r;
-}
+// where the GELU derivatives wait for the backward pass (NIC_Q16_DSTORE): 0 = as bf16 pairs packed like the B fragments (8 registers per hidden layer; one
+// v_cvt_pk per pair in the forward pass, a shift / mask + multiply per value in the backward pass), 1 = as the fp32 values they are (16 registers per layer: no
+// conversion, no unpacking, packed multiplies) where the register budget of two waves per SIMD allows - NOT a rounding point of the mode then
+#ifndef NIC_Q16_DSTORE
+#define NIC_Q16_DSTORE 0
+#endif
+__device__ __forceinline__ void pin4(f32x4& f) { asm volatile("" : "+v"(f)); }
 // acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
 template <int NT, bool ZERO = false, int PFQ = NIC_T16_PF, class LoadA>
 __device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, LoadA&& load_a) {
@@ -530,14 +526,8 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #ifndef NIC_Q16_PIN
 #define NIC_Q16_PIN 2        // pin the derivative fragments: 1 everywhere, 2 with 5 layers and for method 3 (measured, interleaved A/B: pinning costs the 3-layer kernels 0.8 % in 2D, 2 % with method 4)
 #endif
-#ifndef NIC_Q16_D8_ONE
-#define NIC_Q16_D8_ONE 1
-#endif
 #ifndef NIC_Q16_PREADD
 #define NIC_Q16_PREADD 2
-#endif
-#ifndef NIC_Q16_SB
-#define NIC_Q16_SB ((void)0)        // (was __builtin_amdgcn_sched_barrier(0) after every GELU pair: without it 5 layers -0.3 %, method 3 -0.9 %, method 4 -0.35 %, 3 layers 2D unchanged)
 #endif
 
 
@@ -575,24 +565,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? 3 : (Q::NG0 == 1 ? 3 : 0));
 #endif
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
-    // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per layer), except - 5 layers - those of the first RECOMP
-    // layers, the longest-lived ones: they are RECOMPUTED in the backward pass from the layer's input, which still sits in the wave's own
-    // LDS image as the very fragments the forward pass multiplied (same operands, same order: the same pre-activations bit for bit).
-    // 20 more MFMAs and ~300 vector instructions per round buy 16 registers: with them the 5-layer kernel spilled 70 - 150 registers
-    // and moved 9.8 GB of scratch traffic per 4K launch (profiles/r03_c0_pmc.csv: FETCH_SIZE 1.8 GB, WRITE_SIZE 6.0 GB against 0.10 / 0.16 GB).
-    // 5 layers, second form (default): ALL derivatives kept, as 8-bit fixed point (pack_d8: 4 registers per layer) - no recompute at all: the
-    // recompute was 4.3 K of the 27.1 K cycles of a round (ab/q16/stamps_q16.py: phases 7 and 11 against 3 / 5 and the 3-layer kernel's 11)
-#ifdef NIC_Q16_D8
-    constexpr bool D8 = NIC_Q16_D8 != 0 && TRAIN;                     // experiment: derivatives as bytes (changes the mode's rounding points; off)
-#else
-    constexpr bool D8 = false;
-#endif
+    // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per hidden layer), pinned where they are written (pin())
     constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && (NL == 5 || Q::NG0 == 2)) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
-#ifdef NIC_Q16_RECOMP
-    constexpr int RECOMP = NIC_Q16_RECOMP;
-#else
-    constexpr int RECOMP = 0;                                         // every derivative is kept since they are pinned (NIC_Q16_PIN); 2 = the recomputing form
-#endif
     __shared__ __attribute__((aligned(16))) __bf16 smemq[TRAIN ? S::TOTAL : S::OFF_IMG];
     lds_bf* const sm = (lds_bf*)smemq;
 
@@ -611,7 +585,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             const float v = p.W[0][o * Q::CIN + (ch >= 0 ? ch : 0)];
             return ch >= 0 ? v : 0.f;                                   // the constant-one column stays zero: b1 is added in fp32
         },
-        [&](int idx, float v) { sm[S::OFF_W1 + idx] = (__bf16)v; });
+        [&](int idx, float v) { sm[S::OFF_W1 + idx] = bf16_1(v); });
 #ifdef NIC_STAMPS
     unsigned long long stamp_t1, stamp_t2;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t1)::"memory");
@@ -625,14 +599,14 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 const float v = Wk[o * kH + hid16(ps < kH ? ps : 0)];
                 return ps < kH ? v : 0.f;
             },
-            [&](int idx, float v) { sm[S::OFF_WH + k * S::WSZ + idx] = (__bf16)v; });
+            [&](int idx, float v) { sm[S::OFF_WH + k * S::WSZ + idx] = bf16_1(v); });
     }
     stage_all<4 * LDH, 512>(tid,
         [&](int idx) {
             const int c = idx / LDH, ps = idx - c * LDH;
             return (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
         },
-        [&](int idx, float v) { sm[S::OFF_WO + idx] = (__bf16)v; });
+        [&](int idx, float v) { sm[S::OFF_WO + idx] = bf16_1(v); });
 #ifdef NIC_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t2)::"memory");
 #endif
@@ -754,8 +728,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
         for (int it = it_begin; it < it_begin + it_len; ++it) {
             // ================= forward =================
-            bf16x8 dpk[D8 ? 1 : NH + 1][2];                                   // GELU derivatives of every hidden activation, bf16, packed like the B fragments
-            uint32_t dq[D8 ? NH + 1 : 1][4];                                  // .. or (D8) as bytes: dword t = the four values of row tile t
+            constexpr bool DF32 = NIC_Q16_DSTORE == 1 && Q::NG0 == 1;           // fp32 derivatives (method 3 has no registers for them)
+            bf16x8 dpk[DF32 ? 1 : NH + 1][2];                                 // GELU derivatives of every hidden activation, bf16, packed like the B fragments
+            f32x4 d32[DF32 ? NH + 1 : 1][4];                                  // .. or fp32, by row tile
             float dz3[3];
             float kf[3];                                                      // G1 interpolation fractions of the sample
             {
@@ -851,27 +826,12 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 bf16x8 af[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    if constexpr (D8 && NIC_Q16_D8_ONE) {
-                        // one row tile at a time, packed at once (activation: two dwords, derivative: one): half the live values of the pairwise form
-                        u32x2 hp[2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            f32x4 a1, d1;
-                            gelu_and_grad4(z[2 * s + h], a1, d1);
-                            hp[h] = cvt_half(a1);
-                            if (0 >= RECOMP) dq[0][2 * s + h] = pack_d8(d1);
-                            NIC_Q16_SB;
-                        }
-                        af[s] = join_halves(hp[0], hp[1]);
-                    } else {
-                        f32x4 a4[2], d4[2];
-                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
-                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                        af[s] = cvt_pair(a4[0], a4[1]);
-                        if constexpr (D8) { if (0 >= RECOMP) { dq[0][2 * s] = pack_d8(d4[0]); dq[0][2 * s + 1] = pack_d8(d4[1]); } }
-                        else if (0 >= RECOMP) { dpk[0][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[0][s]); }
-                        NIC_Q16_SB;
-                    }
+                    f32x4 a4[2], d4[2];
+                    gelu_q(z[2 * s], a4[0], d4[0]);
+                    gelu_q(z[2 * s + 1], a4[1], d4[1]);
+                    af[s] = cvt_pair(a4[0], a4[1]);
+                    if constexpr (DF32) { d32[0][2 * s] = d4[0]; d32[0][2 * s + 1] = d4[1]; pin4(d32[0][2 * s]); pin4(d32[0][2 * s + 1]); }
+                    else { dpk[0][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[0][s]); }
                 }
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
@@ -885,26 +845,12 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        if constexpr (D8 && NIC_Q16_D8_ONE) {
-                            u32x2 hp[2];
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                f32x4 a1, d1;
-                                gelu_and_grad4(z[2 * s + h], a1, d1);
-                                hp[h] = cvt_half(a1);
-                                if (k + 1 >= RECOMP) dq[k + 1][2 * s + h] = pack_d8(d1);
-                                NIC_Q16_SB;
-                            }
-                            af[s] = join_halves(hp[0], hp[1]);
-                        } else {
-                            f32x4 a4[2], d4[2];
-                            gelu_and_grad4(z[2 * s], a4[0], d4[0]);
-                            gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                            af[s] = cvt_pair(a4[0], a4[1]);
-                            if constexpr (D8) { if (k + 1 >= RECOMP) { dq[k + 1][2 * s] = pack_d8(d4[0]); dq[k + 1][2 * s + 1] = pack_d8(d4[1]); } }
-                            else if (k + 1 >= RECOMP) { dpk[k + 1][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[k + 1][s]); }
-                            NIC_Q16_SB;
-                        }
+                        f32x4 a4[2], d4[2];
+                        gelu_q(z[2 * s], a4[0], d4[0]);
+                        gelu_q(z[2 * s + 1], a4[1], d4[1]);
+                        af[s] = cvt_pair(a4[0], a4[1]);
+                        if constexpr (DF32) { d32[k + 1][2 * s] = d4[0]; d32[k + 1][2 * s + 1] = d4[1]; pin4(d32[k + 1][2 * s]); pin4(d32[k + 1][2 * s + 1]); }
+                        else { dpk[k + 1][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[k + 1][s]); }
                     }
                 }
                 // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); its input fragments are the
@@ -951,7 +897,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 if (g == 0) {
                     lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) d3_st[c * 16] = (__bf16)dz3[c];
+                    for (int c = 0; c < 3; ++c) d3_st[c * 16] = bf16_1(dz3[c]);
                 }
             }
             wave_lds_fence();
@@ -981,7 +927,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int t = 0; t < 4; ++t) {
                         const s16x4 a = tr4(&wo_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
                         const f32x4 dl = mfma16_bf(join8(a, a), bf, f32x4(0.f));
-                        if constexpr (D8) dzc[t] = dl * unpack_d8(dq[NH][t]);
+                        if constexpr (DF32) dzc[t] = dl * d32[NH][t];
                         else dzc[t] = dl * unpack4(dpk[NH][t >> 1], t & 1);
                     }
                 }
@@ -1037,61 +983,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 }
                 if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
                 STAMP(4 + 2 * j);
-                if (k >= RECOMP) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if constexpr (D8) dzc[t] = acc[t] * unpack_d8(dq[k][t]);
-                        else dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
-                    }
-#ifdef NIC_Q16_SB2
-                    NIC_Q16_SB;
-#endif
-                } else {
-                    // recompute the pre-activation whose GELU produced a_k: layer 1 (k = 0: X image, W1) or hidden layer k - 1 (A_{k-1} image)
-                    const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
-                    lds_bf* const imgw = img0 + wave * S::SPW;
-                    lds_cf* const b_row = opaque(Bs + 4 * g);
-                    f32x4 z[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[k * kH + 16 * t]);
-                    if (k == 0) {
-                        lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
-                        lds_cbf* const x_ld = opaque((lds_cbf*)(imgw + n16 * LDX + 8 * g));
-#pragma unroll
-                        for (int s = 0; s < KF; ++s) {
-                            const bf16x8 bf = ld_frag(&x_ld[32 * s]);
-                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
-                        }
-                        if constexpr (HALF) {
-                            lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
-                            lds_cbf* const x_ld2 = opaque((lds_cbf*)(imgw + n16 * LDX + 32 * KF + 4 * g));
-                            const bf16x8 bf = half_frag(*reinterpret_cast<lds_cs16x4*>(x_ld2));
-                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
-                        }
-                    } else {
-                        lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));
-                        lds_cbf* const a_ld = opaque((lds_cbf*)(imgw + S::OFF_A + (k - 1) * S::ASZ + n16 * LDZ + 8 * g));
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const bf16x8 bf = ld_frag(&a_ld[32 * s]);
-                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w_row[S::OFF_WH + (k - 1) * S::WSZ + 16 * t * LDH + 32 * s]); });
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        f32x4 a4[2], d4[2];
-                        gelu_and_grad4(z[2 * s], a4[0], d4[0]);
-                        gelu_and_grad4(z[2 * s + 1], a4[1], d4[1]);
-                        if constexpr (D8) {                                 // rounded like the kept ones
-                            dzc[2 * s] = acc[2 * s] * unpack_d8(pack_d8(d4[0]));
-                            dzc[2 * s + 1] = acc[2 * s + 1] * unpack_d8(pack_d8(d4[1]));
-                        } else {
-                            const bf16x8 dp = cvt_pair(d4[0], d4[1]);
-                            dzc[2 * s] = acc[2 * s] * unpack4(dp, false);
-                            dzc[2 * s + 1] = acc[2 * s + 1] * unpack4(dp, true);
-                        }
-                        NIC_Q16_SB;
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (DF32) dzc[t] = acc[t] * d32[k][t];
+                    else dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
                 }
             }
             // ---------- phase NH, layer 1: dX = W1^T dZ1 for the grid slots (tile t = slots 4t .. 4t+3); tiles 0 .. NG0T-1 (the G0 channels) keep

@@ -113,7 +113,9 @@ __device__ __forceinline__ Frag2 split_pair(const f32x4& a, const f32x4& b) {   
     return split8(x);
 }
 __device__ __forceinline__ lds_bf* opaque(lds_bf* p) {
+#ifndef NIC_NO_OPAQUE_PTR
     asm volatile("" : "+v"(p));
+#endif
     return p;
 }
 
@@ -149,7 +151,9 @@ struct GridAcc16 {
 // (LDS addresses, PE constants, select masks) is loop-invariant, and left alone the optimiser hoists it all out of the round loop
 // and the macro-tile loop - about 70 registers more than the 256 that two waves per SIMD allow, spilled to scratch.
 __device__ __forceinline__ int opaque_i(int v) {
+#ifndef NIC_NO_OPAQUE_LANE
     asm volatile("" : "+v"(v));
+#endif
     return v;
 }
 

@@ -162,6 +162,41 @@ __device__ __forceinline__ void gelu_and_grad4(const f32x4_t z, f32x4_t& a, f32x
     a = f32x4_t{aa[0], aa[1], ab[0], ab[1]};
     d = f32x4_t{da[0], da[1], db[0], db[1]};
 }
+// The plain 16-bit product modes (NIC_FLAG_BF16 / NIC_FLAG_FP16: fused_q16.hpp) round every activation and derivative to 8 / 11 significant
+// bits, so their GELU does not have to be the 1.5e-7 form above.  Phi(z) ~ 1 / (1 + 2^(z w(z^2))) - the "tanh" form of GELU with the
+// coefficients of w refitted against the erf definition (ab/micro/gelu_probe.hip measures both forms against fp64):
+//   NC = 3: w = c0 + c1 z^2 + c2 z^4 (z^2 clamped at 64: the quartic term would turn the tail around):  |GELU error| <= 3.7e-5, |derivative error| <= 9.3e-5
+//   NC = 2: w = c0 + c1 z^2:                                                                           |GELU error| <= 3.4e-4, |derivative error| <= 6.7e-4
+// (half an ulp of bfloat16 at 1 is 2e-3).  The derivative is the exact derivative of the approximant, Phi + z Phi' with
+// Phi' = -ln2 w'(z) Phi (1 - Phi) - no second exponential.  A value costs ~ 9 (11) multiply-adds + v_exp + v_rcp instead of ~ 18 + v_exp + v_rcp:
+// measured on two waves of one SIMD 43 (53) cycles per value against 61 (ab/micro/gelu_probe.hip; a transcendental is ~ 9, a packed pair 4).
+// Restated by oracle/nic_oracle.py::gelu_sigmoid (the precision-emulating oracle evaluates the same form).
+template <int NC>
+__device__ __forceinline__ void gelu_sig4(const f32x4_t z, f32x4_t& a, f32x4_t& d) {
+    constexpr float LN2 = 0.69314718055994530942f;
+    constexpr float C0 = NC == 3 ? -2.30087589f : -2.3080629f, C1 = NC == 3 ? -1.06770560e-01f : -0.10091118f, C2 = 1.00279102e-03f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x2 x = {z[2 * i], z[2 * i + 1]};
+        f32x2 x2 = x * x, w, q;
+        if constexpr (NC == 3) {
+            x2[0] = fminf(x2[0], 64.f); x2[1] = fminf(x2[1], 64.f);
+            w = pk_fma(pk_fma(f32x2(C2), x2, f32x2(C1)), x2, f32x2(C0));
+            q = pk_fma(pk_fma(f32x2(-5.f * LN2 * C2), x2, f32x2(-3.f * LN2 * C1)), x2, f32x2(-LN2 * C0));
+        } else {
+            w = pk_fma(f32x2(C1), x2, f32x2(C0));
+            q = pk_fma(f32x2(-3.f * LN2 * C1), x2, f32x2(-LN2 * C0));
+        }
+        const f32x2 u = x * w;
+        f32x2 P;
+        P[0] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[0]));         // 2^u = inf -> Phi = 0; 2^u = 0 -> Phi = 1
+        P[1] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[1]));
+        const f32x2 av = x * P;
+        const f32x2 dv = pk_fma(av * (f32x2(1.0f) - P), q, P);
+        a[2 * i] = av[0]; a[2 * i + 1] = av[1];
+        d[2 * i] = dv[0]; d[2 * i + 1] = dv[1];
+    }
+}
 __device__ __forceinline__ float gelu_only(float z) {
     float a, d;
     gelu_and_grad(z, a, d);

@@ -192,13 +192,16 @@ def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor
         import ctypes
         from . import _lib
         lib = _lib.load()
-        key = ("xbuf", str(grad_g0.device), grad_g0.data_ptr(), grad_g1.data_ptr())
+        # the buffer is sized from `small` and the grids' shapes: both are part of the key (a decoder of another depth, or a reallocated gradient
+        # of another shape at the same address, must not reuse a buffer that is too short - the C side cannot check its length)
+        key = ("xbuf", str(grad_g0.device), grad_g0.data_ptr(), grad_g1.data_ptr(), small.numel(), tuple(grad_g0.shape), tuple(grad_g1.shape))
         cached = plan._index.get(key)
         if cached is None:
             sets = (_lib.NicRowSet * 2)(_row_set(plan, 0, grad_g0), _row_set(plan, 1, grad_g1))
             n = small.numel() + sum(int(q.channels) * int(q.nrows) * int(q.row_elems) for q in sets)
             cached = plan._index[key] = (sets, torch.empty(n, dtype=torch.float32, device=grad_g0.device))
         sets, buf = cached
+        assert buf.numel() == small.numel() + sum(int(q.channels) * int(q.nrows) * int(q.row_elems) for q in sets)
         with torch.cuda.device(grad_g0.device):
             st = _lib.stream_ptr(grad_g0.device)
             _lib.check(lib.nic_stripe_pack(_lib.ptr(small), small.numel(), sets, 2, _lib.ptr(buf), st), "nic_stripe_pack")

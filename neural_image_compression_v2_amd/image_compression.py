@@ -275,16 +275,22 @@ class ImageCompression:
         """the unfused forms of the step (when ``loss`` is None) and what follows every step: optimiser, scheduler, clamp"""
         c = self.cfg
         D = c.FP_DIMENSION
-        if loss is not None:
-            pass
-        elif c.DECODER_LINEAR_LAYERS != 3 and not layerwise:
+        if loss is None and c.DECODER_LINEAR_LAYERS != 3 and not layerwise and not getattr(self, "_no_fused_kernel", False):
             # deeper decoders: the tail after the freeze runs the fused op (forward kernel + recompute-backward kernel)
             geo = self._geometry(fl, lod, self.train_sample_number(lod), c.NUM_CROPS, split_bf16=bool(c.TF_SPLIT_BF16), bf16=c.plain_bf16,
                                  noise_mode=_lib.NIC_NOISE_KERNEL if noisy else _lib.NIC_NOISE_NONE, noise_seed=noise_seed, noise_offset=epoch)
-            y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
-            loss = ((y - target) ** 2).mean()
-            self.optimizer.zero_grad()
-            loss.backward()
+            try:
+                y = fused.fused_grid_mlp(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params())
+                loss = ((y - target) ** 2).mean()
+                self.optimizer.zero_grad()
+                loss.backward()
+            except _lib.Unsupported:
+                # a resumed run or a captured fit that reaches the tail without having met the refusal before (depth 2 / 4, other widths):
+                # nothing has been launched; the layer-wise route below serves the rest of the fit
+                self._no_fused_kernel = True
+                loss = None
+        if loss is not None:
+            pass
         else:
             if D == 2:
                 x = self.create_decoder_input_2d(fp, coord, c.NUM_CROPS, fl, lod)
@@ -482,8 +488,14 @@ class ImageCompression:
                 fp = fp_load(fp, c.FP_BITS, torch.float32)
                 stored = False
             ga, gb = fp[2 * fl], fp[2 * fl + 1]
-            if D == 3 and not stored:
-                ga, gb = ga.detach(), gb.detach()           # 3D decodes read the fp32 masters (the 16-bit mirrors are a training-side storage; 2D decodes gather from them)
+            # the decode runs the arithmetic the fit was trained in: plain-bf16 fits (TF_PLAIN_BF16) decode on the plain-bf16 forward kernels and gather
+            # from the same 16-bit mirrors the training step read; split / fp32 fits on the split / fp32 inference kernels; fits that fell back to the
+            # layer-wise fp32 route (no fused kernel for their widths / depth) decode layer-wise in fp32
+            plain = bool(c.plain_bf16)
+            if getattr(self, "_no_fused_kernel", False):
+                self._no_fused_decode = True
+            if D == 3 and not stored and not plain:
+                ga, gb = ga.detach(), gb.detach()           # the 3D split / fp32 kernels read the fp32 masters (16-bit mirrors: plain-bf16 kernels, 2D split kernels)
             run_fused = (lambda geo, org: fused.fused_forward_u8(geo, ga, gb, org, params)) if stored else \
                         (lambda geo, org: fused.fused_forward(geo, ga, gb, org, params))
 
@@ -500,8 +512,9 @@ class ImageCompression:
                     a, b = ga.detach(), gb.detach()
                 return fused.DecoderFunction.apply(fused.encode(geo, a, b, org), *[t.detach() for t in params])
             split = bool(c.TF_SPLIT_BF16)                      # split-bf16 products (every layout's inference kernel; 2 x faster, outputs within 3e-7)
-            # channel counts other than the reference's defaults exist on the plain-bf16 kernels only: their forward pass decodes
-            wide = (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) != (12, 6)
+            # (channel counts other than the reference's defaults have fused kernels in the plain-bf16 family only: without TF_PLAIN_BF16 the fused
+            #  entry points answer NIC_E_UNSUPPORTED for them and `run` decodes layer-wise in fp32 - like such a fit trains)
+            wide = plain
             if div_slice == 1:
                 y = run(self._geometry(fl, mip_level, decode_size, 1, split_bf16=split, bf16=wide), [[0] * D])
                 return y.reshape(*([decode_size] * D), 3)

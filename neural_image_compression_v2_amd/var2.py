@@ -44,11 +44,13 @@ class Settings:
                                          # 5e-6 of the fp32 kernels).  False: fp32 MFMAs throughout
     TF_GRID_BF16: bool = False           # not in the reference: bfloat16 grid STORAGE with fp32 masters (MLP_NUM_DTYPE = 16 is the reference's own route and
                                          # maps the grids to float16, utils.py:301-313; this flag selects bfloat16 instead)
-    TF_PLAIN_BF16: int = -1              # not in the reference: fused training steps in PLAIN bf16 products (NIC_FLAG_BF16: one bf16 value per operand, fp32
+    TF_PLAIN_BF16: int = 0               # not in the reference: fused training steps in PLAIN 16-bit products (NIC_FLAG_BF16: one bf16 value per operand, fp32
                                          # accumulation; every layout, 3 or 5 Linear layers; 1.5x (2D) / 2.6x (3D) faster than the split products; outputs
-                                         # within 2e-4 of fp32 arithmetic, fits within 0.001 dB of the split fits - BASELINE.json's "bf16").  1 / True: on,
-                                         # 0 / False: off, -1 (default): on for 3D fits - the reference's own sweeps, where the split-bf16 kernels are the
-                                         # one-wave-per-SIMD family of round 1 - and off in 2D (`plain_bf16`).  Decodes stay on the split / fp32 inference kernels
+                                         # within 2e-4 of fp32 arithmetic, gradients ~5e-3 - BASELINE.json's "bf16").  1 / True: on; 0 / False (default): the
+                                         # reference-faithful arithmetic (split-bf16 = fp32-equivalent, or fp32 with TF_SPLIT_BF16 = False) in every
+                                         # dimension; -1: on for 3D fits only (round 3's default).  A fit decodes in the arithmetic it trained in (`decode_image`)
+    TF_PLAIN_FP16: bool = False          # with TF_PLAIN_BF16: the products run on fp16 operands instead (NIC_FLAG_FP16: the reference's own 16-bit type,
+                                         # utils.py:301-313, `v_mfma_f32_16x16x32_f16`; dZ carried with a static power-of-two loss scale) - BASELINE config 3's "fp16"
     DECODER_LINEAR_LAYERS: int = 3       # not in the reference (depth is hard-coded at 3, image_compression.py:57-64): 5 = the "4 x 64" decoder of
                                          # the north star; served by the fused 2D step / decode with TF_SPLIT_BF16
     TF_DEVICE_SAMPLER: bool = False      # not in the reference: LOD and crop origins from the counter-based device sampler (sampler.py) and targets
@@ -85,7 +87,7 @@ class Settings:
 
     @property
     def plain_bf16(self) -> bool:
-        """TF_PLAIN_BF16 resolved: explicit 0 / 1 (False / True), or by dimension when left at -1"""
+        """TF_PLAIN_BF16 resolved: explicit 0 / 1 (False / True), or by dimension when set to -1"""
         v = int(self.TF_PLAIN_BF16)
         return self.FP_DIMENSION == 3 if v < 0 else bool(v)
 

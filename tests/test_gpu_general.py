@@ -304,8 +304,8 @@ def test_multilevel_field_trains_and_decodes(dev):
 GRAPH_CASES = [
     dict(IMAGE_SIZE=512, NUM_CROPS=4),                                                             # 2D, split-bf16 products: fused_train16
     dict(IMAGE_SIZE=512, NUM_CROPS=4, TF_PLAIN_BF16=1),                                            # 2D, plain bf16: fused_q16
-    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=4, CROP_MIP_LEVEL=5, NUM_CROPS=8),   # the reference's sweep shape, method 4 (plain bf16 by default)
-    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, CROP_MIP_LEVEL=5, NUM_CROPS=8, MLP_NUM_DTYPE=16),   # method 3, float16 grid storage
+    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=4, CROP_MIP_LEVEL=5, NUM_CROPS=8, TF_PLAIN_BF16=1),   # the reference's sweep shape, method 4
+    dict(IMAGE_SIZE=64, IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, CROP_MIP_LEVEL=5, NUM_CROPS=8, MLP_NUM_DTYPE=16, TF_PLAIN_BF16=1),   # method 3, float16 grid storage
     dict(IMAGE_SIZE=512, NUM_CROPS=2, TF_PLAIN_BF16=1, DECODER_LINEAR_LAYERS=5, TF_GRID_BF16=True),   # the north star's decoder and storage
 ]
 

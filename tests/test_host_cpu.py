@@ -535,14 +535,16 @@ def test_counter_based_sampler_host_functions_match_the_oracle(lib):
 
 
 def test_settings_resolve_the_product_precision():
-    """TF_PLAIN_BF16 = -1 (default): plain-bf16 products for 3D fits (the reference's sweeps; PSNR-equivalent to the split fits, tests/test_gpu_bf16.py),
-    split products in 2D; explicit values win; the argv form of the reference's flag system parses it"""
+    """TF_PLAIN_BF16 = 0 (default): the reference-faithful arithmetic (split products = fp32-equivalent) in every dimension - plain 16-bit products are an
+    opt-in; -1 keeps round 3's "3D only" resolution; explicit values win; the argv form of the reference's flag system parses it"""
     from neural_image_compression_v2_amd.var2 import Settings
     assert Settings().plain_bf16 is False
-    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3).plain_bf16 is True and Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=4).plain_bf16 is True
-    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=2).plain_bf16 is False              # method 2: a 3D volume flattened to a 2D pyramid
-    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, TF_PLAIN_BF16=False).plain_bf16 is False and Settings(TF_PLAIN_BF16=True).plain_bf16 is True
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3).plain_bf16 is False and Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=4).plain_bf16 is False
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, TF_PLAIN_BF16=-1).plain_bf16 is True and Settings(TF_PLAIN_BF16=-1).plain_bf16 is False
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=2, TF_PLAIN_BF16=-1).plain_bf16 is False   # method 2: a 3D volume flattened to a 2D pyramid
+    assert Settings(IMAGE_DIMENSION=3, COMPRESSION_METHOD=3, TF_PLAIN_BF16=True).plain_bf16 is True and Settings(TF_PLAIN_BF16=True).plain_bf16 is True
     assert Settings.from_argv(["TF_PLAIN_BF16=1"]).plain_bf16 is True and Settings.from_argv(["IMAGE_DIMENSION=3", "TF_PLAIN_BF16=0"]).plain_bf16 is False
+    assert Settings().TF_PLAIN_FP16 is False and Settings.from_argv(["TF_PLAIN_FP16=True"]).TF_PLAIN_FP16 is True
 
 
 def test_light_cosine_scheduler_is_torchs_bit_for_bit():
