@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 7
+#define NIC_ABI_VERSION 8
 
 enum {
     NIC_OK = 0,
@@ -359,6 +359,36 @@ int nic_fused_forward_backward_img_dev(const nic_path_desc *desc, const float *g
                                        void *stream);
 int nic_adam_multi_dev(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, const float *sched,
                        int64_t sched_rows, const int64_t *step_dev, void *stream);
+
+/* ---- MULTI-LEVEL fused step (no reference semantics: the reference reads ONE level pair per sample, fp_def.py:24-34, image_compression.py:76-79;
+ *      BASELINE.json config 2 names a "16-level grid", SURVEY 0 asks for the level count as a kernel parameter).  A sample gathers from the first
+ *      `levels` level pairs AT ONCE and the decoder sees their encodings concatenated:
+ *          x = [enc_0 | .. | enc_{levels-1} | lod],  enc_l = [G0_l corners (4 C) | blended G1_l (C) | PE_l (2 P)]
+ *      enc_l being exactly what create_g0_g1 (fp_def.py:115-145) computes for pair l at step_number 2^(desc->log2_step - 2 l) (image_compression.py:79:
+ *      4^-(l+1) at mip 0), the positional encoding on THAT pair's G1-cell coordinate; Cin = levels (5 C + 2 P) + 1 (decoder weights mlp->w[0] = [H, Cin]).
+ *      2D (desc->dim = 2, method = 1), fp32 grids, plain-bf16 products (the arithmetic of NIC_FLAG_BF16: csrc/fused_q16.hpp), in-kernel / tensor / no
+ *      noise, ONE launch: gathers, noise, decoder forward, loss, backward, one atomic flush per touched cell and pair.  Fused kernels exist for
+ *      (levels, C, n_linear) in {(2,4,3), (3,4,3), (5,4,3), (2,4,5), (3,4,5), (2,12,3), (3,12,3)} with P = 6, H = 64 (what fits the 160 KB of LDS beside the
+ *      [64, Cin] weight image); everything else returns NIC_E_UNSUPPORTED (the caller composes nic_encode x levels + the general decoder instead).
+ *      desc->g0_nodes / g1_nodes are ignored (pairs carry their own); desc->extent, num_crops, origins, noise, loss_scale, sample_base as in
+ *      nic_fused_forward_backward.  Gradients are ADDED into pairs->g0_grad / g1_grad (dense fp32 tensors of the grids' shapes, zeroed by the caller). */
+#define NIC_ML_MAX_LEVELS 5
+typedef struct nic_ml_pairs {
+    int32_t levels;                               /* 2 .. NIC_ML_MAX_LEVELS */
+    int32_t reserved;
+    const float *g0[NIC_ML_MAX_LEVELS];           /* [C, ny, nx] fp32 */
+    const float *g1[NIC_ML_MAX_LEVELS];
+    float *g0_grad[NIC_ML_MAX_LEVELS];            /* training entry point only */
+    float *g1_grad[NIC_ML_MAX_LEVELS];
+    int32_t g0_nodes[NIC_ML_MAX_LEVELS][2];       /* nodes per axis (x, y) */
+    int32_t g1_nodes[NIC_ML_MAX_LEVELS][2];
+} nic_ml_pairs;
+int nic_fused_ml_forward_backward(const nic_path_desc *desc, const nic_ml_pairs *pairs, const int32_t *origins, const nic_mlp *mlp,
+                                  const float *noise, const float *target, float *y, float *loss, const nic_mlp_grads *grads,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+/* forward only (decode): y = [N, 3] */
+int nic_fused_ml_forward(const nic_path_desc *desc, const nic_ml_pairs *pairs, const int32_t *origins, const nic_mlp *mlp, float *y,
+                         void *stream);
 
 /* ---- multi-GPU, stripe-sharded grids (no reference counterpart - the reference is single-device): the per-step exchange buffer
  *      [small | boundary rows of G0 | boundary rows of G1].  `small` = the head of the flat gradient bucket (loss + decoder gradients,

@@ -19,6 +19,9 @@ SOURCES = ["simple_kernels.hip", "decoder_general.hip", "fused_capi.hip", "fused
 # non-default FEATURE_PYRAMID_CHANNELS / PE_CHANNELS on the plain-bf16 kernels: (layout, C, P), one translation unit each
 SOURCES += [f"fused_qc_{l}_{c}_{p}.hip" for l, c, p in [(1, 4, 6), (1, 8, 6), (1, 16, 6), (1, 12, 4), (1, 12, 8), (2, 4, 6), (2, 8, 6), (2, 16, 6), (2, 12, 4), (2, 12, 8),
                                                          (3, 4, 6), (3, 8, 6), (4, 4, 6), (4, 8, 6), (4, 16, 6)]]
+# multi-level layouts (fused_q16.hpp::QML): (levels, C, n_linear), one translation unit each
+ML_LIST = [(2, 4, 3), (3, 4, 3), (5, 4, 3), (2, 4, 5), (3, 4, 5), (2, 12, 3), (3, 12, 3)]
+SOURCES += [f"fused_ml_{l}_{c}_{n}.hip" for l, c, n in ML_LIST]
 HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", "fused_q16.hpp", "fused_q16_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results that vector instructions consume may live in the architectural VGPRs instead of bouncing
 # through v_accvgpr_read / write (split training kernel: 656 -> 423 of them, -0.7 %; fp32 2D 18 -> 0 spills; 3D 170 -> 115 / 135 -> 85)
@@ -58,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # 4K launch 1.420 -> 1.401 ms, 128^3 method 3 0.483 -> 0.461, method 4 0.426 -> 0.417 (interleaved A/B, identical results); the split and fp32
         # kernels do not move (or lose 1 %): they keep the default
         # (fused_t16: 2.122 -> 2.104 ms on the final kernel; it did not move before the 16x16x16 products went in)
-        if os.path.basename(s).startswith("fused_q") or os.path.basename(s) == "fused_t16.hip":
+        if os.path.basename(s).startswith(("fused_q", "fused_ml_")) or os.path.basename(s) == "fused_t16.hip":
             extra.append("-fno-slp-vectorize")
         cmd = [hipcc, *FLAGS, *extra, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)

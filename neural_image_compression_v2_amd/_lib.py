@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 7
+NIC_ABI_VERSION = 8
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -50,6 +50,16 @@ class NicMlp(ctypes.Structure):
 
 class NicMlpGrads(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p * 5), ("b", ctypes.c_void_p * 5)]
+
+
+NIC_ML_MAX_LEVELS = 5
+
+
+class NicMlPairs(ctypes.Structure):
+    """struct nic_ml_pairs (include/nicv2_hip.h): the level pairs of a multi-level launch"""
+    _fields_ = [("levels", ctypes.c_int32), ("reserved", ctypes.c_int32), ("g0", ctypes.c_void_p * NIC_ML_MAX_LEVELS), ("g1", ctypes.c_void_p * NIC_ML_MAX_LEVELS),
+                ("g0_grad", ctypes.c_void_p * NIC_ML_MAX_LEVELS), ("g1_grad", ctypes.c_void_p * NIC_ML_MAX_LEVELS),
+                ("g0_nodes", (ctypes.c_int32 * 2) * NIC_ML_MAX_LEVELS), ("g1_nodes", (ctypes.c_int32 * 2) * NIC_ML_MAX_LEVELS)]
 
 
 NIC_ADAM_MAX_TENSORS = 32
@@ -125,6 +135,8 @@ SIGNATURES = {
     "nic_rgbx_interleave": (_I, [_P, _L, _P, _P]),
     "nic_rgbx_downsample2": (_I, [_P, _I, _I, _P, _P]),
     "nic_rgbx_resample_axis": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "nic_fused_ml_forward_backward": (_I, [_D, ctypes.POINTER(NicMlPairs), _P, _M, _P, _P, _P, _P, _G, _P, _SZ, _P]),
+    "nic_fused_ml_forward": (_I, [_D, ctypes.POINTER(NicMlPairs), _P, _M, _P, _P]),
     "nic_stripe_pack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
     "nic_stripe_unpack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
 }

@@ -352,6 +352,26 @@ int reduce_q16_any(int layout, int n_linear, const nic_path_desc* d, const float
         default: return reduce_q16<4>(n_linear, partials, n_rec, g, loss, loss_scale, s);
     }
 }
+// multi-level layouts (fused_q16.hpp::QML): (levels, C, n_linear) with P = 6, one translation unit each (fused_ml_*.hip)
+#define NIC_ML_LIST(X) X(2, 4, 3) X(3, 4, 3) X(5, 4, 3) X(2, 4, 5) X(3, 4, 5) X(2, 12, 3) X(3, 12, 3)
+int ml_rec(int lv, int c, int nl) {
+#define X(L, C, N) if (lv == L && c == C && nl == N) return ml_record_floats<L, C, N>();
+    NIC_ML_LIST(X)
+#undef X
+    return 0;
+}
+int launch_ml_any(int lv, int c, int nl, int pe, int mode, const FusedParams& p, int grid, hipStream_t s) {
+#define X(L, C, N) if (lv == L && c == C && nl == N) return launch_ml<L, C, N>(pe, mode, p, grid, s);
+    NIC_ML_LIST(X)
+#undef X
+    return NIC_E_UNSUPPORTED;
+}
+int reduce_ml_any(int lv, int c, int nl, int pe, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
+#define X(L, C, N) if (lv == L && c == C && nl == N) return reduce_ml<L, C, N>(pe, partials, n_rec, g, loss, loss_scale, s);
+    NIC_ML_LIST(X)
+#undef X
+    return NIC_E_UNSUPPORTED;
+}
 FusedParams zero_params() {
     FusedParams p;
     ::memset(static_cast<void*>(&p), 0, sizeof(p));
@@ -444,9 +464,91 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     return reduce(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
 }
 
+// geometry, pairs and decoder of a multi-level launch -> FusedParams (regular 16 x 1 cell tiles of pair 0, whole macro-tiles: the flush of the
+// multi-level kernels sums runs of lanes, which the edge-tile / packed / grouped schedules of the single-pair kernels would break up)
+int fill_ml(FusedParams& p, const nic_path_desc* d, const nic_ml_pairs* pr, const int32_t* origins, const nic_mlp* mlp, const float* noise, bool training,
+            int& rec) {
+    if (!d || !pr || !origins || !mlp) return NIC_E_NULL;
+    if (d->dim != 2 || d->method != 1 || d->hidden != kH || d->pe_channels != kP) return NIC_E_UNSUPPORTED;
+    if (d->pe_mode != NIC_PE_TRIANGULAR && d->pe_mode != NIC_PE_SINUSOIDAL) return NIC_E_UNSUPPORTED;
+    if (pr->levels < 2 || pr->levels > NIC_ML_MAX_LEVELS) return NIC_E_UNSUPPORTED;
+    if (!mlp_ok(mlp)) return depth_unsupported(mlp) ? NIC_E_UNSUPPORTED : NIC_E_NULL;
+    rec = ml_rec(pr->levels, d->channels, mlp_depth(mlp));
+    if (rec == 0) return NIC_E_UNSUPPORTED;
+    if (d->flags & (NIC_FLAG_GRID_BF16 | NIC_FLAG_GRID_FP16)) return NIC_E_UNSUPPORTED;       // fp32 grids
+    nic_path_desc d2 = *d;
+    for (int a = 0; a < 2; ++a) { d2.g0_nodes[a] = pr->g0_nodes[0][a]; d2.g1_nodes[a] = pr->g1_nodes[0][a]; }
+    int rc = check_geometry(&d2, training);
+    if (rc) return rc;
+    if (d->log2_step - 2 * (pr->levels - 1) < -16) return NIC_E_ARG;
+    if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
+    for (int l = 0; l < pr->levels; ++l) {
+        if (!pr->g0[l] || !pr->g1[l] || (training && (!pr->g0_grad[l] || !pr->g1_grad[l]))) return NIC_E_NULL;
+        for (int a = 0; a < 2; ++a)
+            if (pr->g0_nodes[l][a] < 2 || pr->g1_nodes[l][a] < 2) return NIC_E_SHAPE;
+        if ((int64_t)pr->g0_nodes[l][0] * pr->g0_nodes[l][1] >= (int64_t)1 << 30 || 10 * (int64_t)pr->g1_nodes[l][0] * pr->g1_nodes[l][1] >= (int64_t)1 << 30)
+            return NIC_E_UNSUPPORTED;
+    }
+    const int cin = pr->levels * (5 * d->channels + 2 * d->pe_channels) + 1;
+    fill_encode(p, &d2, FusedInfo{0, rec, 16, 1, 1, cin, 8}, pr->g0[0], pr->g1[0], origins, noise, false);
+    if (p.edge_lw >= 0) {                                              // the remainder column along x as one more column of regular tiles
+        p.full_x += 1;
+        p.edge_lw = -1;
+        p.tiles_main = (int64_t)p.full_x * p.tiles_y * p.tiles_z;
+        p.tiles_per_crop = p.tiles_main;
+        p.n_tiles = p.tiles_per_crop * d->num_crops;
+    }
+    fill_mlp(p, mlp);
+    for (int l = 0; l < pr->levels; ++l) {
+        MlPair& m = p.ml[l];
+        m.g0.p = pr->g0[l]; m.g0.nx = pr->g0_nodes[l][0]; m.g0.ny = pr->g0_nodes[l][1]; m.g0.nz = 1; m.g0.plane = (int64_t)m.g0.nx * m.g0.ny;
+        m.g1.p = pr->g1[l]; m.g1.nx = pr->g1_nodes[l][0]; m.g1.ny = pr->g1_nodes[l][1]; m.g1.nz = 1; m.g1.plane = (int64_t)m.g1.nx * m.g1.ny;
+        m.g0_grad = training ? pr->g0_grad[l] : nullptr;
+        m.g1_grad = training ? pr->g1_grad[l] : nullptr;
+    }
+    p.g0_grad = p.ml[0].g0_grad; p.g1_grad = p.ml[0].g1_grad;
+    p.grid_kind = 0;
+    return NIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nic_fused_ml_forward_backward(const nic_path_desc* d, const nic_ml_pairs* pairs, const int32_t* origins, const nic_mlp* mlp, const float* noise,
+                                  const float* target, float* y, float* loss, const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!target || !loss || !grads || !workspace) return NIC_E_NULL;
+    FusedParams p = zero_params();
+    int rec = 0;
+    int rc = fill_ml(p, d, pairs, origins, mlp, noise, true, rec);
+    if (rc) return rc;
+    p.target = target; p.y = y;
+    p.partials = (float*)workspace;
+    p.rg_log2 = 0; p.rg0_log2 = 0; p.seg_split = 0; p.preadd_y = 0;    // whole macro-tiles, one segment
+    if (p.n_tiles >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
+    const int grid = grid_for(p.n_tiles, 1, 8, d->max_workgroups);
+    if (workspace_bytes < (size_t)grid * rec * sizeof(float)) return NIC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_ml_any(pairs->levels, d->channels, p.n_linear, d->pe_mode, MODE_TRAIN_MSE, p, grid, s);
+    if (rc) return rc;
+    return reduce_ml_any(pairs->levels, d->channels, p.n_linear, d->pe_mode, p.partials, grid, *grads, loss, d->loss_scale, s);
+}
+
+int nic_fused_ml_forward(const nic_path_desc* d, const nic_ml_pairs* pairs, const int32_t* origins, const nic_mlp* mlp, float* y, void* stream) {
+    if (!y) return NIC_E_NULL;
+    if (d && d->noise_mode != NIC_NOISE_NONE) return NIC_E_ARG;        // decoding never adds noise (image_compression.py:307-346)
+    FusedParams p = zero_params();
+    int rec = 0;
+    int rc = fill_ml(p, d, pairs, origins, mlp, nullptr, false, rec);
+    if (rc) return rc;
+    p.y = y;
+    balance_units(p, 1, 8);
+    if ((p.n_tiles << p.rg_log2) >= ((int64_t)1 << 30)) return NIC_E_UNSUPPORTED;
+    p.seg_split = 0;
+    return launch_ml_any(pairs->levels, d->channels, p.n_linear, d->pe_mode, MODE_INFER, p, grid_for(p.n_tiles << p.rg_log2, 1, 8, d->max_workgroups),
+                         (hipStream_t)stream);
+}
 
 size_t nic_workspace_bytes(const nic_path_desc* d) {
     int rec = fused_info<3>().rec;                                   // the largest record
@@ -460,6 +562,9 @@ size_t nic_workspace_bytes(const nic_path_desc* d) {
         if (q16_rec(l, 5) > rec) rec = q16_rec(l, 5);
 #define X(L, C, P) if (q16_record_floats_cp<L, C, P>() > rec) rec = q16_record_floats_cp<L, C, P>();
     NIC_CP_LIST(X)
+#undef X
+#define X(L, C, N) if (ml_record_floats<L, C, N>() > rec) rec = ml_record_floats<L, C, N>();
+    NIC_ML_LIST(X)
 #undef X
     const size_t fused = (size_t)(cu_count() / 8 * 8) * rec * sizeof(float) + (1u << 20);   // one record per workgroup, at most one workgroup per CU (+ 1 MiB: diagnostic builds)
     const size_t psnr = 1024 * sizeof(double);

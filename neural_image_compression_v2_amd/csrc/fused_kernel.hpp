@@ -77,11 +77,18 @@ enum { MODE_INFER = 0, MODE_TRAIN_MSE = 1, MODE_TRAIN_DY = 2, MODE_TRAIN_IMG = 3
 #ifndef NIC_FK_PIN
 #define NIC_FK_PIN 1
 #endif
+// one level pair of a multi-level launch (fused_q16.hpp::QML)
+struct MlPair {
+    GridView g0, g1;
+    float* g0_grad;
+    float* g1_grad;
+};
 struct FusedParams {
     nic_path_desc d;
     GridView g0, g1;
     float* g0_grad;
     float* g1_grad;
+    MlPair ml[NIC_ML_MAX_LEVELS];      // multi-level layouts only: pair l (pair 0 repeats g0 / g1 / their gradients); pair l's step is 2^(d.log2_step - 2 l)
     const int32_t* origins;
     const float* W[NIC_MAX_LINEAR];
     const float* b[NIC_MAX_LINEAR];

@@ -1,0 +1,5 @@
+// multi-level plain-bf16 fused kernels (fused_q16.hpp::QML): 5 level pairs, FEATURE_PYRAMID_CHANNELS = 4, 3 Linear layers
+#include "fused_q16_launch.hpp"
+namespace nic {
+NIC_INSTANTIATE_ML(5, 4, 3)
+}

@@ -47,7 +47,7 @@ __host__ __device__ constexpr int align4(int v) { return (v + 3) & ~3; }
 // dimension g >> 1 [P / 2] | LOD (g = 0) / the constant one (g = 1) | zero padding.  C = 12, P = 6: the 20 slots of fused_train16.hpp.
 template <int C_, int P_, int PE_>
 struct QL2D {
-    static constexpr int DIM = 2, C = C_, P = P_, PE = PE_, GQ = C / 4, PH = P / 2;
+    static constexpr int DIM = 2, C = C_, P = P_, PE = PE_, GQ = C / 4, PH = P / 2, LEVELS = 1;
     static constexpr int CIN = 5 * C + 2 * P + 1, K0 = 4, K1 = 4, NG0 = 1;
     static constexpr bool TETRA = false;
     static constexpr int NGS = C + GQ, T0 = align4(NGS), NS = align4(T0 + PH + 1);
@@ -73,7 +73,7 @@ __host__ __device__ constexpr int tail3d_channel(int j, int g, int pe0) {      /
 // tetrahedral G0 (fp_def.py:107-112, 187-223): Cin = 5 C + 19: corner g [C] | G1 [GQ] | tail [5] | zero padding
 template <int C_, int P_>
 struct QL<4, C_, P_> {
-    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4;
+    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4, LEVELS = 1;
     static constexpr int CIN = 5 * C + 19, K0 = 4, K1 = 8, NG0 = 1;
     static constexpr bool TETRA = true;
     static constexpr int PE = NIC_PE_SINUSOIDAL;                                // fp_def.py:208
@@ -89,7 +89,7 @@ struct QL<4, C_, P_> {
 // 8 raw G0 corners (fp_def.py:89-104, 148-184): Cin = 9 C + 19: corners 2g, 2g + 1 [2 C] (dx = g >> 1, dy = g & 1, dz = s / C) | G1 [GQ] | tail [5] | zero padding
 template <int C_, int P_>
 struct QL<3, C_, P_> {
-    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4;
+    static constexpr int DIM = 3, C = C_, P = P_, GQ = C / 4, LEVELS = 1;
     static constexpr int CIN = 9 * C + 19, K0 = 8, K1 = 8, NG0 = 2;
     static constexpr bool TETRA = false;
     static constexpr int PE = NIC_PE_TRIANGULAR;                                // fp_def.py:169
@@ -103,19 +103,44 @@ struct QL<3, C_, P_> {
     }
 };
 
+// MULTI-LEVEL 2D (multilevel.MultiLevelField; BASELINE config 2's "16-level grid" as the extension it is: the reference reads ONE level pair per sample,
+// fp_def.py:24-34): a sample reads the first LV level pairs at once and the decoder sees their encodings concatenated,
+//     x = [enc_0 | .. | enc_{LV-1} | lod],  enc_l = [G0_l corners (4 C) | blended G1_l (C) | PE_l (2 P)]  at step_number 4^-(l+1) (image_compression.py:79-100)
+// i.e. Cin = LV (5 C + 2 P) + 1.  A quarter's slots: its corner g of EVERY pair [LV x C] | its G1 channels of every pair [LV x GQ] | zero padding to a multiple
+// of 4 | its PE rows of every pair [LV x PH] | LOD (g = 0) / the constant one (g = 1) | zero padding: the grid slots still come first (the dX tiles), and LV = 1
+// is QL2D's layout.  All samples of a lane's macro-tile share their cell in EVERY pair (cells nest: 4^(l+1) pixels, absolute alignment).
+template <int LV, int C_, int P_, int PE_>
+struct QML {
+    static constexpr int DIM = 2, C = C_, P = P_, PE = PE_, GQ = C / 4, PH = P / 2, LEVELS = LV;
+    static constexpr int PER = 5 * C + 2 * P;                                   // channels of one pair's encoding
+    static constexpr int CIN = LV * PER + 1, K0 = 4, K1 = 4, NG0 = LV;          // NG0: gather / atomic addresses of G0 per lane (one per pair)
+    static constexpr bool TETRA = false;
+    static constexpr int NGS = LV * (C + GQ), T0 = align4(NGS), NS = align4(T0 + LV * PH + 1);
+    static_assert(C % 4 == 0 && P % 2 == 0 && C >= 4 && P >= 2 && LV >= 2 && LV <= NIC_ML_MAX_LEVELS, "multi-level layout");
+    __host__ __device__ static constexpr int slot_channel(int s, int g) {
+        if (s < LV * C) return (s / C) * PER + C * g + s % C;
+        if (s < NGS) return ((s - LV * C) / GQ) * PER + 4 * C + GQ * g + (s - LV * C) % GQ;
+        if (s < T0) return kSlotZero;
+        if (s < T0 + LV * PH) return ((s - T0) / PH) * PER + 5 * C + PH * g + (s - T0) % PH;
+        if (s == T0 + LV * PH) return g == 0 ? CIN - 1 : (g == 1 ? kSlotOne : kSlotZero);
+        return kSlotZero;
+    }
+};
+
 template <class Q>
 struct QInfo {
     static constexpr int NG0V = Q::C * Q::NG0;                 // raw G0 values / G0 gradient sums per lane
-    static constexpr int NG1V = Q::GQ * Q::K1;                 // raw G1 values / G1 gradient sums per lane
+    static constexpr int NG1V = Q::GQ * Q::K1 * Q::LEVELS;     // raw G1 values / G1 gradient sums per lane
     static constexpr int NGS = Q::NGS;                         // grid slots of a quarter (they come first)
     static constexpr int KF = Q::NS / 8;                       // full k-steps of layer 1 (32 columns each)
     static constexpr bool HALF = (Q::NS % 8) != 0;             // + a compact half k-step (4 slots per quarter, 16 columns)
     static constexpr int KP = 4 * Q::NS;                       // columns of the X / W1 images
     static constexpr int NDX = (NGS + 3) / 4;                  // dX tiles (4 slots each) that hold grid slots
     static constexpr int NT1 = 2 * KF;                         // 32x32 tiles of dW1's full k-steps: tile to * KF + tk (row half to, column block tk)
-    static constexpr int LD1 = KP <= 80 ? 80 : 144;            // W1 image row stride: 160- / 288-byte rows spread b128 row reads over the banks (ab/w16/banks.py)
+    static constexpr int LD1 = ((KP - 16 + 63) / 64) * 64 + 16;   // W1 image row stride = 16 mod 64 elements (80, 144, 208, 272): 160- / 288- / .. byte rows spread b128 row reads over the banks (ab/w16/banks.py)
     static constexpr int LDX = KP + 8;
-    static_assert(Q::NS % 4 == 0 && NT1 >= 2 && NT1 <= 8 && KP <= 128, "layout");
+    static constexpr int T1W = (NT1 + 7) / 8;                  // dW1 tiles per wave when every wave owns tiles (NT1 > 4)
+    static_assert(Q::NS % 4 == 0 && NT1 >= 2 && NT1 <= 16 && KP <= 256 && (KP <= 128 ? LD1 == (KP <= 80 ? 80 : 144) : true), "layout");
     // in-kernel noise (oracle/nic_oracle.py::kernel_noise_quarter): the real slots of a quarter, in slot order, take six-bit fields 0, 1, 2, ..;
     // 20 fields per generator block, quarter g consumes blocks NBLK g ..
     __host__ __device__ static constexpr int noise_index(int s) { return s < NGS ? s : (s >= Q::T0 && Q::slot_channel(s, 0) != kSlotZero ? NGS + (s - Q::T0) : -1); }
@@ -153,7 +178,7 @@ struct LdsQ {
     static constexpr int OFF_IMG = (OFF_B + 2 * NBIAS + 7) & ~7;
     // per wave (bf16 elements): X [16][LDX] | A_k [16][LDZ] x NH | DZ [16][LDZ] x DZB | dZ_out [4][16]
     static constexpr int OFF_A = 16 * LDX, ASZ = 16 * LDZ, OFF_DZ = OFF_A + NH * ASZ;
-    static constexpr int SCRATCH = 2 * 64 * (I::NG0V + I::NG1V + 1);     // the head of the wave region doubles as fp32 scratch of the flush (group sums, pre-add)
+    static constexpr int SCRATCH = Q::LEVELS > 1 ? 0 : 2 * 64 * (I::NG0V + I::NG1V + 1);     // the head of the wave region doubles as fp32 scratch of the flush (group sums, pre-add; not multi-level)
     static constexpr int spw_of(int dzb) { return (OFF_DZ + dzb * ASZ > SCRATCH ? OFF_DZ + dzb * ASZ : SCRATCH) + 64; }
     static constexpr int DZB = (OFF_IMG + 8 * spw_of(2)) * 2 <= 163840 ? 2 : 1;      // two DZ buffers where they fit (not: method 3 with 5 layers)
     static constexpr int OFF_D3 = spw_of(DZB) - 64;                                  // behind the scratch: its fourth row stays zero
@@ -161,7 +186,10 @@ struct LdsQ {
     static constexpr int TOTAL = OFF_IMG + 8 * SPW;
     // phases of the backward pass: j = 0 .. NH - 1 = hidden layer NH - 1 - j, j = NH = layer 1.  Phase j belongs to half j & 1, accumulator slot j >> 1;
     // with more than 4 dW1 tiles (6 or 8: wide input layouts) wave w owns tile w: the half that does not own phase NH keeps it in an extra slot
-    static constexpr int NACC = (NH + 2) / 2 + (I::NT1 > 4 ? 1 : 0), XSLOT = (NH + 2) / 2;
+    // multi-level layouts (up to 16 dW1 tiles): wave w owns tiles w, w + 8 in slots of their own behind the hidden layers' (D1SLOT ..)
+    static constexpr bool ML = Q::LEVELS > 1;
+    static constexpr int D1SLOT = (NH + 1) / 2;
+    static constexpr int NACC = ML ? D1SLOT + I::T1W : (NH + 2) / 2 + (I::NT1 > 4 ? 1 : 0), XSLOT = (NH + 2) / 2;
     static constexpr int TAIL_HALF = (NH + 1) & 1;                                   // HALF: the 16-column tail of dW1 goes to the half that idles in phase NH
     __host__ __device__ static constexpr int dz_buf(int store) { return DZB == 2 ? (store & 1) : 0; }   // store 0: a_NH (forward), store 1 + j: the dZ of phase j
     static_assert(TOTAL * 2 <= 163840, "LDS");
@@ -218,13 +246,8 @@ __device__ __forceinline__ void gelu_q(const f32x4& z, f32x4& a, f32x4& d) {
     if constexpr (NIC_Q16_GELU == 0) gelu_and_grad4(z, a, d);
     else gelu_sig4<NIC_Q16_GELU>(z, a, d);
 }
-// where the GELU derivatives wait for the backward pass (NIC_Q16_DSTORE): 0 = as bf16 pairs packed like the B fragments (8 registers per hidden layer; one
-// v_cvt_pk per pair in the forward pass, a shift / mask + multiply per value in the backward pass), 1 = as the fp32 values they are (16 registers per layer: no
-// conversion, no unpacking, packed multiplies) where the register budget of two waves per SIMD allows - NOT a rounding point of the mode then
-#ifndef NIC_Q16_DSTORE
-#define NIC_Q16_DSTORE 0
-#endif
-__device__ __forceinline__ void pin4(f32x4& f) { asm volatile("" : "+v"(f)); }
+// (Measured and dropped: the GELU derivatives kept as the fp32 values they are instead of packed bf16 pairs - 16 registers per hidden layer, no conversion,
+// no unpacking: 5 layers 2.128 -> 2.125 ms, 3 layers 1.258 -> 1.288: the instructions it saves are paid back in register moves.)
 // acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
 template <int NT, bool ZERO = false, int PFQ = NIC_T16_PF, class LoadA>
 __device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, LoadA&& load_a) {
@@ -317,6 +340,161 @@ __device__ __forceinline__ void gather_cell_q(const FusedParams& p, uint32_t off
         for (int i = 0; i < (DO_G0 ? QInfo<Q>::NG0V : 0); ++i) raw.g0[i] = widen16(h0[i], is_bf);
 #pragma unroll
         for (int i = 0; i < (DO_G1 ? QInfo<Q>::NG1V : 0); ++i) raw.g1[i] = widen16(h1[i], is_bf);
+    }
+}
+
+// ---- multi-level layouts (QML): cell offsets, gathers and input slots of every pair; fp32 grids
+template <class Q>
+__device__ __forceinline__ void cell_offsets_ml(const FusedParams& p, const int (&q)[3], uint32_t (&off0)[Q::LEVELS], uint32_t (&off1)[Q::LEVELS]) {
+#pragma unroll
+    for (int l = 0; l < Q::LEVELS; ++l) {
+        const int e = p.d.log2_step - 2 * l;
+        const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
+        const GridView& a = p.ml[l].g0;
+        const GridView& b = p.ml[l].g1;
+        off0[l] = (uint32_t)a.at(clampi(ax.i0, 0, a.nx - 2), clampi(ay.i0, 0, a.ny - 2), 0);
+        off1[l] = (uint32_t)b.at(clampi(ax.i1, 0, b.nx - 2), clampi(ay.i1, 0, b.ny - 2), 0);
+    }
+}
+template <class Q, bool DO_G0, bool DO_G1>
+__device__ __forceinline__ void gather_cell_ml(const FusedParams& p, const uint32_t (&off0)[Q::LEVELS], const uint32_t (&off1)[Q::LEVELS], int g, CellRawQ<Q>& raw) {
+    const int dx = g >> 1, dy = g & 1;
+#pragma unroll
+    for (int l = 0; l < Q::LEVELS; ++l) {
+        if constexpr (DO_G0) {
+            const GridView& a = p.ml[l].g0;
+            uint32_t ob = (off0[l] + (uint32_t)a.at(dx, dy, 0)) * 4u;
+            const uint32_t pb = (uint32_t)a.plane * 4u;
+            const char* base = reinterpret_cast<const char*>(a.p);
+#pragma unroll
+            for (int c = 0; c < Q::C; ++c, ob += pb) raw.g0[l * Q::C + c] = *reinterpret_cast<const float*>(base + ob);
+        }
+        if constexpr (DO_G1) {
+            const GridView& b = p.ml[l].g1;
+            const uint32_t pb = (uint32_t)b.plane * 4u;
+            const char* base = reinterpret_cast<const char*>(b.p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t ob = (off1[l] + (uint32_t)b.at(q >> 1, q & 1, 0) + (uint32_t)(Q::GQ * g) * (uint32_t)b.plane) * 4u;
+#pragma unroll
+                for (int cc = 0; cc < Q::GQ; ++cc, ob += pb) raw.g1[(l * 4 + q) * Q::GQ + cc] = *reinterpret_cast<const float*>(base + ob);
+            }
+        }
+    }
+}
+template <class Q>
+__device__ __forceinline__ void encode_ml(const FusedParams& p, const int (&q)[3], int g, float (&xs)[Q::NS], const CellRawQ<Q>& raw) {
+    constexpr int L = Q::LEVELS, C = Q::C, GQ = Q::GQ, PH = Q::PH, T0 = Q::T0;
+    const nic_path_desc& d = p.d;
+#pragma unroll
+    for (int c = 0; c < L * C; ++c) xs[c] = raw.g0[c];
+#pragma unroll
+    for (int s = Q::NGS; s < T0; ++s) xs[s] = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int e = d.log2_step - 2 * l;                                   // this pair's step_number (image_compression.py:79)
+        const Axis ax = axis_coords(q[0], e), ay = axis_coords(q[1], e);
+        const float c = (g >> 1) ? ay.t1 : ax.t1;                            // PE rows PH (g & 1) + i of dimension g >> 1 on THIS pair's G1-cell coordinate
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const int r = PH * (g & 1) + i;
+            float v;
+            if (Q::PE == NIC_PE_TRIANGULAR) {
+                v = tri_pe_row(c, r, Q::P);
+            } else {
+                const int k = r >> 1;
+                const float dv = pick_loaded(k == 0, d.pe_div[0], pick_loaded(k == 1, d.pe_div[1], pick_loaded(k == 2, d.pe_div[2], d.pe_div[3])));
+                float sv, cv;
+                sincos_cw(mul_rn(c, dv), sv, cv);
+                v = (r & 1) ? cv : sv;
+            }
+            xs[T0 + l * PH + i] = v;
+        }
+        const G1FactorsT<2> gf = g1_factors<2>(d.g1_weight_mode, ax.k1, ay.k1, 0.f);      // fp_def.py:141-144
+#pragma unroll
+        for (int cc = 0; cc < GQ; ++cc) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                const uint32_t b = (gf.bits >> (3 * c8)) & 7u;
+                float v = raw.g1[(l * 4 + c8) * GQ + cc];
+                v = mul_rn(v, (b & 1u) ? gf.fx[1] : gf.fx[0]);
+                v = mul_rn(v, (b & 2u) ? gf.fy[1] : gf.fy[0]);
+                sum = c8 == 0 ? v : add_rn(sum, v);
+            }
+            xs[L * C + l * GQ + cc] = sum;
+        }
+    }
+    xs[T0 + L * PH] = g == 0 ? d.lod_value : (g == 1 ? 1.0f : 0.f);
+#pragma unroll
+    for (int s = T0 + L * PH + 1; s < Q::NS; ++s) xs[s] = 0.f;
+}
+// Flush of a multi-level macro-tile.  The 16 lanes of a quarter are 16 consecutive cells of pair 0 along x; in pair l they fall into runs of 4^l lanes
+// with the SAME cell (one run from pair 2 on): the sums of a run are added across its lanes (segmented suffix sums: 4 shuffle steps, keyed by the cell
+// offset - runs are contiguous, so "lane + d has my key" means everything in between has it too) and the run's first lane issues the atomics.
+__device__ __forceinline__ float seg_sum16(float v, const bool (&same)[4], int ln) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float pv = __shfl(v, ln + (1 << k));
+        v += same[k] ? pv : 0.f;
+    }
+    return v;
+}
+template <class Q, int NDX>
+__device__ __forceinline__ void flush_ml(const FusedParams& p, const uint32_t (&off0)[Q::LEVELS], const uint32_t (&off1)[Q::LEVELS], const f32x4 (&dxacc)[NDX],
+                                         const float (&g1s)[QInfo<Q>::NG1V], int ln) {
+    const int n16 = ln & 15, g = ln >> 4;
+#pragma unroll
+    for (int l = 0; l < Q::LEVELS; ++l) {
+#pragma unroll
+        for (int grid = 0; grid < 2; ++grid) {
+            const uint32_t key = grid == 0 ? off0[l] : off1[l];
+            bool same[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = 1 << k;
+                const uint32_t pk = (uint32_t)__shfl((int)key, ln + d);
+                same[k] = n16 + d < 16 && pk == key;
+            }
+            const uint32_t prev_key = (uint32_t)__shfl((int)key, ln - 1);        // unconditionally: a shuffle inside "n16 == 0 || .." reads lanes the branch has switched off (they return 0)
+            const bool head = n16 == 0 || prev_key != key;
+            if (grid == 0) {
+                const GridView& a = p.ml[l].g0;
+                float v[Q::C];
+                uint32_t nz = 0u;
+#pragma unroll
+                for (int c = 0; c < Q::C; ++c) {
+                    v[c] = seg_sum16(dxacc[(l * Q::C + c) >> 2][(l * Q::C + c) & 3], same, ln);
+                    nz |= __builtin_bit_cast(uint32_t, v[c]);
+                }
+                if (head && (nz << 1) != 0u) {
+                    uint32_t ob = (key + (uint32_t)a.at(g >> 1, g & 1, 0)) * 4u;
+                    const uint32_t pb = (uint32_t)a.plane * 4u;
+                    char* gbase = reinterpret_cast<char*>(p.ml[l].g0_grad);
+#pragma unroll
+                    for (int c = 0; c < Q::C; ++c, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[c]);
+                }
+            } else {
+                const GridView& b = p.ml[l].g1;
+                float v[4 * Q::GQ];
+                uint32_t nz = 0u;
+#pragma unroll
+                for (int i = 0; i < 4 * Q::GQ; ++i) {
+                    v[i] = seg_sum16(g1s[l * 4 * Q::GQ + i], same, ln);
+                    nz |= __builtin_bit_cast(uint32_t, v[i]);
+                }
+                if (head && (nz << 1) != 0u) {
+                    const uint32_t pb = (uint32_t)b.plane * 4u;
+                    char* gbase = reinterpret_cast<char*>(p.ml[l].g1_grad);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t ob = (key + (uint32_t)b.at(q >> 1, q & 1, 0) + (uint32_t)(Q::GQ * g) * (uint32_t)b.plane) * 4u;
+#pragma unroll
+                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[q * Q::GQ + cc]);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -529,6 +707,9 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #ifndef NIC_Q16_PREADD
 #define NIC_Q16_PREADD 2
 #endif
+#ifndef NIC_Q16_LOFF
+#define NIC_Q16_LOFF 1        // lane offsets of the round's LDS addresses computed once per launch (see the kernel)
+#endif
 
 
 // =====================================================================================================
@@ -562,8 +743,10 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     // method 4: 0.616 / 0.558 / 0.543 ms; method 3: 0.525 / 0.539 / 0.601 (spills)
     // (second half of round 3: with the derivatives pinned method 3 keeps both grids' raw values too - 5 spilled registers instead of the 48 that made
     //  hoisting lose: 0.552 -> 0.517 ms at 128^3, 0.585 -> 0.52 with 16-bit grids; its 5-layer form still spills with them: not hoisted there)
-    constexpr int HOIST = !TRAIN ? 3 : (NL == 3 ? 3 : (Q::NG0 == 1 ? 3 : 0));
+    // multi-level layouts re-fetch (their raw values are L x (C + 4 GQ) registers beside as many gradient sums)
+    constexpr int HOIST = !TRAIN ? 3 : (Q::LEVELS > 1 ? 0 : (NL == 3 ? 3 : (Q::NG0 == 1 ? 3 : 0)));
 #endif
+    constexpr bool ML = Q::LEVELS > 1;
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
     // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per hidden layer), pinned where they are written (pin())
     constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && (NL == 5 || Q::NG0 == 2)) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
@@ -572,6 +755,24 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The lane-dependent parts of the round's LDS addresses, computed ONCE per launch and kept in 9 registers (element offsets; the wave's image region
+    // included where the address is wave-private).  The phases of a round re-derive their lane ids from an opaque copy of the lane number (opaque_i: left
+    // alone, the optimiser hoists everything computed from them, ~ 70 registers), which made every pointer of a round cost its own mask / shift / multiply /
+    // add chain - ~ 185 of the ~ 2 400 instructions of a 5-layer round: with the offsets at hand a pointer is one add.
+    constexpr bool LOFF = NIC_Q16_LOFF != 0 && TRAIN && (Q::LEVELS == 1 || NIC_Q16_LOFF == 2);
+    int lo_rH = 0, lo_r1 = 0, lo_rX = 0, lo_rZ = 0, lo_tH = 0, lo_t1 = 0, lo_b44 = 0, lo_tZ = 0, lo_tX = 0;
+    if constexpr (LOFF) {
+        const int n16 = lane & 15, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h32 = lane >> 5, cg = (lane >> 4) & 1;
+        lo_rH = opaque_i(n16 * LDH + 8 * g);                                       // row n16, columns 8 g ..: forward A fragments of the 64-column weight images
+        lo_r1 = LD1 == LDH ? lo_rH : opaque_i(n16 * LD1 + 8 * g);                  // .. of W1
+        lo_rX = opaque_i(wave * S::SPW + n16 * LDX + 8 * g);                       // this wave's X image: fragment stores
+        lo_rZ = opaque_i(wave * S::SPW + n16 * LDZ + 8 * g);                       // .. its A_k / DZ images
+        lo_tH = opaque_i((4 * g + q4) * LDH + 8 * p4);                             // transposed reads of the hidden weight images
+        lo_t1 = LD1 == LDH ? lo_tH : opaque_i((4 * g + q4) * LD1 + 8 * p4);        // .. of W1
+        lo_b44 = opaque_i(wave * S::SPW + 4 * q4 * LDZ + 16 * g + 4 * p4);         // 4x4x4 B operands out of this wave's DZ image
+        lo_tZ = opaque_i((4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4);             // 32x32x16 operands out of the DZ / A_k images of a source wave
+        lo_tX = opaque_i((4 * q4 + 2 * h32) * LDX + 16 * cg + 4 * p4);             // .. out of its X image
+    }
 #ifdef NIC_STAMPS
     unsigned long long stamp_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
@@ -685,6 +886,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
         float g1s[I::NG1V];                                                  // G1 gradient sums of the cell
         f32x4 dxacc[NDX];                                                    // tiles 0 .. NG0T-1: the cell's G0 gradient sums (persistent over the rounds)
         uint32_t blk_off0, blk_off1;
+        uint32_t mo0[Q::LEVELS], mo1[Q::LEVELS];                             // multi-level: the cell offsets of every pair
         CellRawQ<Q> raw;
         {
             const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
@@ -721,18 +923,23 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
             for (int t = 0; t < NDX; ++t) dxacc[t] = f32x4(0.f);
             const int qb[3] = {blk[0] << p.lm, blk[1] << p.lm, blk[2] << p.lm};
-            cell_offsets<Q>(p, qb, blk_off0, blk_off1);
-            gather_cell_q<Q, true, true>(p, blk_off0, blk_off1, g, raw);
+            if constexpr (ML) {
+                cell_offsets_ml<Q>(p, qb, mo0, mo1);
+                blk_off0 = mo0[0]; blk_off1 = mo1[0];
+                gather_cell_ml<Q, true, true>(p, mo0, mo1, g, raw);
+            } else {
+                cell_offsets<Q>(p, qb, blk_off0, blk_off1);
+                gather_cell_q<Q, true, true>(p, blk_off0, blk_off1, g, raw);
+            }
         }
         STAMP(12);
 
         for (int it = it_begin; it < it_begin + it_len; ++it) {
             // ================= forward =================
-            constexpr bool DF32 = NIC_Q16_DSTORE == 1 && Q::NG0 == 1;           // fp32 derivatives (method 3 has no registers for them)
-            bf16x8 dpk[DF32 ? 1 : NH + 1][2];                                 // GELU derivatives of every hidden activation, bf16, packed like the B fragments
-            f32x4 d32[DF32 ? NH + 1 : 1][4];                                  // .. or fp32, by row tile
+            bf16x8 dpk[NH + 1][2];                                            // GELU derivatives of every hidden activation, bf16, packed like the B fragments
             float dz3[3];
             float kf[3];                                                      // G1 interpolation fractions of the sample
+            int qs[2] = {0, 0};                                               // multi-level: its coordinates (the fractions of every pair are re-derived in the backward pass)
             {
                 const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4;
                 // ---------- which sample does this lane own in this round
@@ -783,17 +990,18 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 }
                 // ---------- input slots
                 float xs[NS];
-                encode_q<Q>(p, q, g, xs, kf, raw);
+                if constexpr (ML) { encode_ml<Q>(p, q, g, xs, raw); qs[0] = q[0]; qs[1] = q[1]; }
+                else encode_q<Q>(p, q, g, xs, kf, raw);
                 add_noise_q<Q>(nsrc, (uint64_t)(p.d.sample_base + n), n, g, xs);
                 STAMP(0);
                 lds_bf* const imgw = img0 + wave * S::SPW;
-                lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LDH + 8 * g));                       // 64-column weight images: row n16, columns 8 g ..
+                lds_cbf* const w_row = opaque((lds_cbf*)(sm + (LOFF ? lo_rH : n16 * LDH + 8 * g)));                       // 64-column weight images: row n16, columns 8 g ..
                 lds_cf* const b_row = opaque(Bs + 4 * g);
                 f32x4 z[4];
                 // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n] + b1[o]
                 {
-                    lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 8 * g));
-                    lds_bf* const x_st = opaque(imgw + n16 * LDX + 8 * g);                                // fragment stores: row n, columns 32 s + 8 g
+                    lds_cbf* const w1_row = opaque((lds_cbf*)(sm + S::OFF_W1 + (LOFF ? lo_r1 : n16 * LD1 + 8 * g)));
+                    lds_bf* const x_st = LOFF ? opaque(img0 + lo_rX) : opaque(imgw + n16 * LDX + 8 * g);                                // fragment stores: row n, columns 32 s + 8 g
 #pragma unroll
                     for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[16 * t]);
 #pragma unroll
@@ -804,8 +1012,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
                     }
                     if constexpr (HALF) {   // slots 8 KF .. 8 KF + 3: compact columns 32 KF + 4 g + j
-                        lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 32 * KF + 4 * g));
-                        lds_bf* const x_st2 = opaque(imgw + n16 * LDX + 32 * KF + 4 * g);
+                        lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + 32 * KF + (LOFF ? lo_r1 - 4 * g : n16 * LD1 + 4 * g)));
+                        lds_bf* const x_st2 = LOFF ? opaque(img0 + 32 * KF + lo_rX - 4 * g) : opaque(imgw + n16 * LDX + 32 * KF + 4 * g);
                         const float xv[8] = {xs[8 * KF], xs[8 * KF + 1], xs[8 * KF + 2], xs[8 * KF + 3], 0.f, 0.f, 0.f, 0.f};
                         const bf16x8 bf = cvt8(xv);
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf);
@@ -830,12 +1038,12 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     gelu_q(z[2 * s], a4[0], d4[0]);
                     gelu_q(z[2 * s + 1], a4[1], d4[1]);
                     af[s] = cvt_pair(a4[0], a4[1]);
-                    if constexpr (DF32) { d32[0][2 * s] = d4[0]; d32[0][2 * s + 1] = d4[1]; pin4(d32[0][2 * s]); pin4(d32[0][2 * s + 1]); }
-                    else { dpk[0][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[0][s]); }
+                    dpk[0][s] = cvt_pair(d4[0], d4[1]);
+                    if (PIN) pin(dpk[0][s]);
                 }
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
-                    lds_bf* const a_st = opaque(imgw + S::OFF_A + k * S::ASZ + n16 * LDZ + 8 * g);
+                    lds_bf* const a_st = LOFF ? opaque(img0 + S::OFF_A + k * S::ASZ + lo_rZ) : opaque(imgw + S::OFF_A + k * S::ASZ + n16 * LDZ + 8 * g);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) z[t] = ld4(&b_row[(k + 1) * kH + 16 * t]);
 #pragma unroll
@@ -849,8 +1057,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         gelu_q(z[2 * s], a4[0], d4[0]);
                         gelu_q(z[2 * s + 1], a4[1], d4[1]);
                         af[s] = cvt_pair(a4[0], a4[1]);
-                        if constexpr (DF32) { d32[k + 1][2 * s] = d4[0]; d32[k + 1][2 * s + 1] = d4[1]; pin4(d32[k + 1][2 * s]); pin4(d32[k + 1][2 * s + 1]); }
-                        else { dpk[k + 1][s] = cvt_pair(d4[0], d4[1]); if (PIN) pin(dpk[k + 1][s]); }
+                        dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
+                        if (PIN) pin(dpk[k + 1][s]);
                     }
                 }
                 // ---------- output layer (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); its input fragments are the
@@ -858,7 +1066,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 float yv[3];
                 {
                     lds_cbf* const wo_row = opaque((lds_cbf*)(sm + S::OFF_WO + (n16 < 3 ? n16 : 3) * LDH + 8 * g));
-                    lds_bf* const dz_st = opaque(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + n16 * LDZ + 8 * g);
+                    lds_bf* const dz_st = LOFF ? opaque(img0 + S::OFF_DZ + S::dz_buf(0) * S::ASZ + lo_rZ) : opaque(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + n16 * LDZ + 8 * g);
                     f32x4 z3;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -907,7 +1115,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             {
                 const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, g = ln >> 4;
                 lds_bf* const imgw = img0 + wave * S::SPW;
-                lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                lds_cbf* const dz_b44 = LOFF ? opaque((lds_cbf*)(img0 + S::OFF_DZ + S::dz_buf(0) * S::ASZ + lo_b44)) : opaque((lds_cbf*)(imgw + S::OFF_DZ + S::dz_buf(0) * S::ASZ + 4 * q4 * LDZ + 16 * g + 4 * p4));
                 {   // dW_out[c][pos = lane] += sum_n dZ_out[c][n] a_last[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
                     lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (ln & 3) * 16));
                     s16x4 bh[4], ah[4];
@@ -927,8 +1135,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int t = 0; t < 4; ++t) {
                         const s16x4 a = tr4(&wo_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
                         const f32x4 dl = mfma16_bf(join8(a, a), bf, f32x4(0.f));
-                        if constexpr (DF32) dzc[t] = dl * d32[NH][t];
-                        else dzc[t] = dl * unpack4(dpk[NH][t >> 1], t & 1);
+                        dzc[t] = dl * unpack4(dpk[NH][t >> 1], t & 1);
                     }
                 }
             }
@@ -943,8 +1150,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
                     lds_bf* const imgw = img0 + wave * S::SPW;
                     if (S::DZB == 1) wave_lds_fence();                         // one buffer: this wave's dW_out / db reads of it are issued before it is overwritten
-                    lds_cbf* const wh_tr = opaque((lds_cbf*)(sm + S::OFF_WH + k * S::WSZ + (4 * g + q4) * LDH + 8 * p4));
-                    lds_bf* const dz_st = opaque(imgw + DZO + n16 * LDZ + 8 * g);
+                    lds_cbf* const wh_tr = opaque((lds_cbf*)(sm + S::OFF_WH + k * S::WSZ + (LOFF ? lo_tH : (4 * g + q4) * LDH + 8 * p4)));
+                    lds_bf* const dz_st = LOFF ? opaque(img0 + DZO + lo_rZ) : opaque(imgw + DZO + n16 * LDZ + 8 * g);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
@@ -958,7 +1165,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     }
                     wave_lds_fence();
                     {   // db[pos = lane] += sum_n dZ[pos][n]: 4x4x4 MFMAs against a block of ones
-                        lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + DZO + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                        lds_cbf* const dz_b44 = LOFF ? opaque((lds_cbf*)(img0 + DZO + lo_b44)) : opaque((lds_cbf*)(imgw + DZO + 4 * q4 * LDZ + 16 * g + 4 * p4));
                         const short one = (ln & 3) == k ? (short)0x3F80 : (short)0;      // A[i][.] = 1 for output row i = k only
                         const s16x4 ones = {one, one, one, one};
                         s16x4 bh[4];
@@ -972,8 +1179,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 barrier();                                                     // every wave's dZ image of this phase is in place
                 if (kh == (j & 1)) {   // dW_hidden[k] tile (to, tk) += sum over the samples of all eight waves of dZ[o][n] a_k[i][n]
                     const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
-                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZO + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
-                    lds_cbf* const a_t32 = opaque((lds_cbf*)(img0 + S::OFF_A + k * S::ASZ + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
+                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZO + 32 * to + (LOFF ? lo_tZ : (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
+                    lds_cbf* const a_t32 = opaque((lds_cbf*)(img0 + S::OFF_A + k * S::ASZ + 32 * tk + (LOFF ? lo_tZ : (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
                         const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
@@ -984,18 +1191,15 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
                 STAMP(4 + 2 * j);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if constexpr (DF32) dzc[t] = acc[t] * d32[k][t];
-                    else dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
-                }
+                for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
             }
             // ---------- phase NH, layer 1: dX = W1^T dZ1 for the grid slots (tile t = slots 4t .. 4t+3); tiles 0 .. NG0T-1 (the G0 channels) keep
             // their running sums over the rounds in the product's C operand; the dZ1 fragments are the dZ1 image of dW1
             constexpr int DZ1 = S::OFF_DZ + S::dz_buf(1 + NH) * S::ASZ;
             {
                 const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
-                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
-                lds_bf* const dz_st = opaque(img0 + wave * S::SPW + DZ1 + n16 * LDZ + 8 * g);
+                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (LOFF ? lo_t1 : (4 * g + q4) * LD1 + 8 * p4)));
+                lds_bf* const dz_st = LOFF ? opaque(img0 + DZ1 + lo_rZ) : opaque(img0 + wave * S::SPW + DZ1 + n16 * LDZ + 8 * g);
                 if (S::DZB == 1) wave_lds_fence();
 #pragma unroll
                 for (int t = NG0T; t < NDX; ++t) dxacc[t] = f32x4(0.f);
@@ -1009,6 +1213,23 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     });
                 }
                 // G1 slots I::NG0V .. + GQ - 1: registers of tile NG0T (and the next one when GQ = 4 .. never: NG0V is a multiple of 4, GQ <= 4)
+                if constexpr (ML) {
+#pragma unroll
+                    for (int l = 0; l < Q::LEVELS; ++l) {
+                        const int e = p.d.log2_step - 2 * l;
+                        const Axis ax = axis_coords(qs[0], e), ay = axis_coords(qs[1], e);
+                        const G1FactorsT<2> gf = g1_factors<2>(p.d.g1_weight_mode, ax.k1, ay.k1, 0.f);
+#pragma unroll
+                        for (int c8 = 0; c8 < 4; ++c8) {
+                            const float w = g1_corner_factor<2>(gf, c8);
+#pragma unroll
+                            for (int cc = 0; cc < Q::GQ; ++cc) {
+                                const int sl = I::NG0V + l * Q::GQ + cc;
+                                g1s[(l * 4 + c8) * Q::GQ + cc] = fmaf(dxacc[sl >> 2][sl & 3], w, g1s[(l * 4 + c8) * Q::GQ + cc]);
+                            }
+                        }
+                    }
+                } else {
                 const G1FactorsT<D> gf = g1_factors<D>(p.d.g1_weight_mode, kf[0], kf[1], kf[2]);
 #pragma unroll
                 for (int c8 = 0; c8 < Q::K1; ++c8) {
@@ -1016,24 +1237,43 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int cc = 0; cc < Q::GQ; ++cc) g1s[c8 * Q::GQ + cc] = fmaf(dxacc[(I::NG0V + cc) >> 2][(I::NG0V + cc) & 3], w, g1s[c8 * Q::GQ + cc]);
                 }
+                }
             }
             // not hoisted: the next round's raw values are fetched HERE - in flight across the dW1 phase and the round-end barrier, where
             // few registers are live, and spread over the waves' drift - instead of at the head of the round, where all eight waves of the
             // CU would queue 36+ scattered loads each on its one texture-address path at the same moment (+6.5 K cycles per round)
             if (!HG0 || !HG1) {
                 const int g = opaque_i(lane) >> 4;
-                gather_cell_q<Q, !HG0, !HG1>(p, blk_off0, blk_off1, g, raw);
+                if constexpr (ML) gather_cell_ml<Q, !HG0, !HG1>(p, mo0, mo1, g, raw);
+                else gather_cell_q<Q, !HG0, !HG1>(p, blk_off0, blk_off1, g, raw);
             }
             STAMP(11);
             barrier();
             {
                 const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
-                if constexpr (I::NT1 <= 4) {
+                if constexpr (S::ML) {
+                    // multi-level layouts: wave w owns tiles w, w + 8 (row half tile / KF, column block tile % KF) over all eight source waves
+#pragma unroll
+                    for (int i = 0; i < I::T1W; ++i) {
+                        const int tile1 = wave + 8 * i;
+                        if (tile1 < I::NT1) {                                  // wave-uniform
+                            const int t1o = tile1 / KF, t1k = tile1 - t1o * KF;
+                            lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + 32 * t1o + (LOFF ? lo_tZ : (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
+                            lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + 32 * t1k + (LOFF ? lo_tX : (4 * q4 + 2 * h32) * LDX + 16 * cg + 4 * p4)));
+#pragma unroll
+                            for (int v = 0; v < 8; ++v) {
+                                const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
+                                const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
+                                accW[S::D1SLOT + i] = mfma_bf(a, b, accW[S::D1SLOT + i]);
+                            }
+                        }
+                    }
+                } else if constexpr (I::NT1 <= 4) {
                     if (kh == (NH & 1) && T4 < I::NT1) {
                         // dW1, the columns of the full k-steps: tile T4 = (row half T4 / KF, column block T4 % KF) over all eight source waves
                         const int t1o = T4 / KF, t1k = T4 - t1o * KF;
-                        lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * t1o + 16 * cg + 4 * p4));
-                        lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * t1k + 16 * cg + 4 * p4));
+                        lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + 32 * t1o + (LOFF ? lo_tZ : (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
+                        lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + 32 * t1k + (LOFF ? lo_tX : (4 * q4 + 2 * h32) * LDX + 16 * cg + 4 * p4)));
 #pragma unroll
                         for (int v = 0; v < 8; ++v) {
                             const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
@@ -1044,8 +1284,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 } else if (wave < I::NT1) {
                     // 6 or 8 tiles: wave w owns tile w = (row half w / KF, column block w % KF) over all eight source waves
                     const int t1o = wave / KF, t1k = wave - t1o * KF;
-                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + (4 * q4 + 2 * h32) * LDZ + 32 * t1o + 16 * cg + 4 * p4));
-                    lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * q4 + 2 * h32) * LDX + 32 * t1k + 16 * cg + 4 * p4));
+                    lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + DZ1 + 32 * t1o + (LOFF ? lo_tZ : (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
+                    lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + 32 * t1k + (LOFF ? lo_tX : (4 * q4 + 2 * h32) * LDX + 16 * cg + 4 * p4)));
                     f32x16 c = kh == (NH & 1) ? accW[NH >> 1] : accW[S::XSLOT];
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
@@ -1077,7 +1317,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
-        if (TRAIN) {
+        if constexpr (TRAIN && ML) {
+            flush_ml<Q, NDX>(p, mo0, mo1, dxacc, g1s, opaque_i(lane));
+        } else if constexpr (TRAIN) {
             const int ln = opaque_i(lane), g = ln >> 4;
             combine_g1_lanes_q<Q>(g1s, blk_off1, blk, ln, lw, packed, pk, pk_lc);
             bool flush = true;
@@ -1227,7 +1469,8 @@ __global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const fl
                 // phase NH: the tile's owner wave and accumulator slot (LdsQ)
                 int w, slot;
                 const int tile = (po >> 5) * KF + (r >> 5);
-                if (I::NT1 <= 4) { w = 4 * (NH & 1) + tile; slot = NH >> 1; }
+                if (S::ML) { w = tile & 7; slot = S::D1SLOT + (tile >> 3); }
+                else if (I::NT1 <= 4) { w = 4 * (NH & 1) + tile; slot = NH >> 1; }
                 else { w = tile; slot = (w >> 2) == (NH & 1) ? NH >> 1 : S::XSLOT; }
                 off0 = S::REC_W + (w * S::NACC + slot) * 1024 + tile32(po & 31, r & 31);
             } else {

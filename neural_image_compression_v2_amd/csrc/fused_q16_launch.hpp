@@ -48,4 +48,29 @@ static int reduce_q16_nl(const float* partials, int n_rec, nic_mlp_grads g, floa
     template <>                                                                                                                  \
     int q16_record_floats_cp<METHOD, C, P>() { return LdsQ<QL<METHOD, C, P>, 3>::REC; }
 
+// multi-level layouts (QML<LV, C, 6, pe>): the training step on a target tensor and the forward pass, both positional encodings; one translation unit per
+// (LV, C, NL)
+#define NIC_INSTANTIATE_ML(LV, C, NL)                                                                                            \
+    template <>                                                                                                                  \
+    int launch_ml<LV, C, NL>(int pe_mode, int mode, const FusedParams& p, int grid, hipStream_t s) {                             \
+        const dim3 g(grid), b(512);                                                                                              \
+        if (pe_mode == NIC_PE_TRIANGULAR) {                                                                                      \
+            if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<QML<LV, C, 6, NIC_PE_TRIANGULAR>, MODE_TRAIN_MSE, NL>), g, b, 0, s, p); \
+            else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_q16_kernel<QML<LV, C, 6, NIC_PE_TRIANGULAR>, MODE_INFER, NL>), g, b, 0, s, p);    \
+            else return NIC_E_UNSUPPORTED;                                                                                       \
+        } else {                                                                                                                 \
+            if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<QML<LV, C, 6, NIC_PE_SINUSOIDAL>, MODE_TRAIN_MSE, NL>), g, b, 0, s, p); \
+            else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_q16_kernel<QML<LV, C, 6, NIC_PE_SINUSOIDAL>, MODE_INFER, NL>), g, b, 0, s, p);    \
+            else return NIC_E_UNSUPPORTED;                                                                                       \
+        }                                                                                                                        \
+        return (int)hipGetLastError();                                                                                           \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int reduce_ml<LV, C, NL>(int pe_mode, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
+        return pe_mode == NIC_PE_TRIANGULAR ? reduce_q16_nl<QML<LV, C, 6, NIC_PE_TRIANGULAR>, NL>(partials, n_rec, g, loss, loss_scale, s)     \
+                                            : reduce_q16_nl<QML<LV, C, 6, NIC_PE_SINUSOIDAL>, NL>(partials, n_rec, g, loss, loss_scale, s);    \
+    }                                                                                                                            \
+    template <>                                                                                                                  \
+    int ml_record_floats<LV, C, NL>() { return LdsQ<QML<LV, C, 6, NIC_PE_TRIANGULAR>, NL>::REC; }
+
 }  // namespace nic

@@ -17,6 +17,13 @@ template <int METHOD>
 int reduce_q16(int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
 template <int METHOD>
 int q16_record_floats(int n_linear);
+// .. multi-level layouts QML<LV, C, 6, pe> (fused_ml_*.hip): LV level pairs per sample, n_linear NL
+template <int LV, int C, int NL>
+int launch_ml(int pe_mode, int mode, const FusedParams& p, int grid, hipStream_t s);
+template <int LV, int C, int NL>
+int reduce_ml(int pe_mode, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s);
+template <int LV, int C, int NL>
+int ml_record_floats();
 // .. with non-default channel counts C = FEATURE_PYRAMID_CHANNELS, P = PE_CHANNELS (3 Linear layers; fused_qc_*.hip)
 template <int METHOD, int C, int P>
 int launch_q16_cp(int mode, const FusedParams& p, int grid, hipStream_t s);

@@ -34,6 +34,9 @@
 #ifndef NIC_T16_HALF16
 #define NIC_T16_HALF16 1
 #endif
+#ifndef NIC_T16_LOFF
+#define NIC_T16_LOFF 26        // rZ | b44 | tZ (bits 1, 3, 4): 4K launch 2.120 -> 2.078 ms (interleaved A/B, 4 rounds); all six offsets 2.078 with 3 spilled registers, rZ alone nothing
+#endif
 #ifndef NIC_T16_PIN
 #define NIC_T16_PIN 0        // bit 0: pin d1, bit 1: pin d2, bit 2: pin d2 in the sinusoidal-PE layout only (all measured: no gain in this kernel, see below)
 #endif
@@ -517,6 +520,19 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
     // number of times - and the remainder dealt out in 2^rg_log2 groups of rounds, so that the last, partly filled step of a small
     // launch costs a fraction of a unit (the reference's default step: 2 120 macro-tiles on 2 048 waves = one step of 16 rounds and
     // 72 macro-tiles in 8 groups of 2 rounds, instead of 5 steps of 4).
+    // lane-dependent parts of the round's LDS addresses kept in registers for the whole launch (NIC_T16_LOFF, a bit per offset: this kernel sits at
+    // 252 - 256 registers, so only the offsets that pay for their register are hoisted; fused_q16.hpp has the full set and the measurement)
+    constexpr int LOFF = NIC_T16_LOFF;
+    int lo_rW = 0, lo_rZ = 0, lo_tW = 0, lo_b44 = 0, lo_tZ = 0, lo_rX = 0;
+    {
+        const int n16 = lane & 15, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h32 = lane >> 5, cg = (lane >> 4) & 1;
+        if constexpr ((LOFF & 1) != 0) lo_rW = opaque_i(n16 * S::LD1 + 8 * g);
+        if constexpr ((LOFF & 2) != 0) lo_rZ = opaque_i(wave * S::SPW + n16 * S::LDZ + 8 * g);
+        if constexpr ((LOFF & 4) != 0) lo_tW = opaque_i((4 * g + q4) * S::LD1 + 8 * p4);
+        if constexpr ((LOFF & 8) != 0) lo_b44 = opaque_i(wave * S::SPW + 4 * q4 * S::LDZ + 16 * g + 4 * p4);
+        if constexpr ((LOFF & 16) != 0) lo_tZ = opaque_i((4 * (wave >> 2)) * S::SPW + (4 * q4 + 2 * h32) * S::LDZ + 16 * cg + 4 * p4);
+        if constexpr ((LOFF & 32) != 0) lo_rX = opaque_i(wave * S::SPW + S::OFF_X + n16 * S::LDX + 8 * g);
+    }
     const int xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3;
   for (int seg = 0; seg < 2; ++seg) {
     const int seg_tile0 = seg ? (int)p.seg_split : 0;
@@ -653,10 +669,10 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
                 {
-                    lds_cbf* const w_row = opaque((lds_cbf*)(sm + n16 * LD1 + 8 * g));                    // W1 and W2 (LD1 == LD2): row n16, columns 8 g ..
-                    lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + n16 * LD1 + 64 + 4 * g));
-                    lds_bf* const x_st = opaque(imgw + S::OFF_X + n16 * LDX + 8 * g);                     // fragment stores: row n, columns 32 s + 8 g
-                    lds_bf* const x_st2 = opaque(imgw + S::OFF_X + n16 * LDX + 64 + 4 * g);
+                    lds_cbf* const w_row = opaque((lds_cbf*)(sm + ((LOFF & 1) ? lo_rW : n16 * LD1 + 8 * g)));                    // W1 and W2 (LD1 == LD2): row n16, columns 8 g ..
+                    lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + 64 + ((LOFF & 1) ? lo_rW - 4 * g : n16 * LD1 + 4 * g)));
+                    lds_bf* const x_st = (LOFF & 32) ? opaque(img0 + lo_rX) : opaque(imgw + S::OFF_X + n16 * LDX + 8 * g);                     // fragment stores: row n, columns 32 s + 8 g
+                    lds_bf* const x_st2 = (LOFF & 32) ? opaque(img0 + 64 + lo_rX - 4 * g) : opaque(imgw + S::OFF_X + n16 * LDX + 64 + 4 * g);
                     f32x4 z[4];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -711,7 +727,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     NIC_T16_SB;
                     // ---------- layer 2
                     lds_cf* const b2_row = opaque(Bs + 4 * g);
-                    lds_bf* const a1_st = opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
+                    lds_bf* const a1_st = (LOFF & 2) ? opaque(img0 + S::OFF_A1 + lo_rZ) : opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) z[t] = ld4(&b2_row[16 * t]);
 #pragma unroll
@@ -739,7 +755,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 float yv[3];
                 {
                     lds_cbf* const w3_row = opaque((lds_cbf*)(sm + S::OFF_W3 + (n16 < 3 ? n16 : 3) * LD3 + 8 * g));
-                    lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);
+                    lds_bf* const dz_st = (LOFF & 2) ? opaque(img0 + lo_rZ) : opaque(imgw + n16 * LDZ + 8 * g);
                     f32x4 z3;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -793,7 +809,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 // 4x4x4 operands (own samples): B = column `lane` of samples 4 q' + r; A = dZ3[c = lane & 3][those samples]
-                lds_cbf* const dz_b44 = opaque((lds_cbf*)(imgw + 4 * q4 * LDZ + 16 * g + 4 * p4));
+                lds_cbf* const dz_b44 = (LOFF & 8) ? opaque((lds_cbf*)(img0 + lo_b44)) : opaque((lds_cbf*)(imgw + 4 * q4 * LDZ + 16 * g + 4 * p4));
                 // ---------- dW3[c][pos = lane] += sum_n dZ3[c][n] a2[pos][n]: 4x4x4 MFMAs over the wave's own 16 samples
                 {
                     lds_cbf* const d3_a44 = opaque((lds_cbf*)(imgw + S::OFF_D3 + (ln & 3) * 16));
@@ -841,8 +857,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 NIC_T16_SB;
                 // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are the dZ2 image of the weight-gradient product
                 {
-                    lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + (4 * g + q4) * LD2 + 8 * p4));
-                    lds_bf* const dz_st = opaque(imgw + n16 * LDZ + 8 * g);
+                    lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + ((LOFF & 4) ? lo_tW : (4 * g + q4) * LD2 + 8 * p4)));
+                    lds_bf* const dz_st = (LOFF & 2) ? opaque(img0 + lo_rZ) : opaque(imgw + n16 * LDZ + 8 * g);
                     f32x4 acc[4];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -888,8 +904,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             {
                 const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
                 // 32x32x16 operands: samples 4 q' + 2 (lane >> 5) + rd of a source wave, columns 32 tile + 16 cg + 4 p4
-                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
-                lds_cbf* const a1_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_A1 + (4 * q4 + 2 * h32) * LDZ + 32 * tk + 16 * cg + 4 * p4));
+                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + 32 * to + ((LOFF & 16) ? lo_tZ : (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
+                lds_cbf* const a1_t32 = opaque((lds_cbf*)(img0 + S::OFF_A1 + 32 * tk + ((LOFF & 16) ? lo_tZ : (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     Frag2 af, bf;
@@ -909,8 +925,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             // Tiles 0..2 (the G0 channels) keep their running sums over the rounds in the product's C operand.
             {
                 const int ln = opaque_i(lane), n16 = ln & 15, g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3;
-                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + (4 * g + q4) * LD1 + 8 * p4));
-                lds_bf* const dz_st = opaque(img0 + wave * S::SPW + n16 * LDZ + 8 * g);
+                lds_cbf* const w1_tr = opaque((lds_cbf*)(sm + S::OFF_W1 + ((LOFF & 4) ? lo_tW : (4 * g + q4) * LD1 + 8 * p4)));
+                lds_bf* const dz_st = (LOFF & 2) ? opaque(img0 + lo_rZ) : opaque(img0 + wave * S::SPW + n16 * LDZ + 8 * g);
                 dxacc[3] = f32x4(0.f);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -939,7 +955,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             NIC_T16_SB;
             {
                 const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
-                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 32 * to + 16 * cg + 4 * p4));
+                lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + 32 * to + ((LOFF & 16) ? lo_tZ : (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
                 lds_cbf* const x_t32 = opaque((lds_cbf*)(img0 + (4 * kh) * S::SPW + S::OFF_X + (4 * q4 + 2 * h32) * LDX + 32 * tk + 16 * cg + 4 * p4));
                 // ---------- dW1: columns 0..63 as the 32x32 tile (to, tk) over the same four source waves ...
 #pragma unroll

@@ -629,6 +629,110 @@ class StepPlan:
 # autograd
 # ------------------------------------------------------------------------------------------------------
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# multi-level fused step (nic_fused_ml_*: several level pairs per sample, csrc/fused_q16.hpp::QML)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+ML_FUSED = {(2, 4, 3), (3, 4, 3), (5, 4, 3), (2, 4, 5), (3, 4, 5), (2, 12, 3), (3, 12, 3)}      # (levels, C, n_linear) with P = 6, H = 64: what fits the LDS
+
+
+def ml_is_fused(levels: int, channels: int, pe_channels: int, hidden: int, n_linear: int) -> bool:
+    return (int(levels), int(channels), int(n_linear)) in ML_FUSED and int(pe_channels) == 6 and int(hidden) == 64
+
+
+def _ml_pairs(fp: Sequence[torch.Tensor], grads: Optional[Sequence[torch.Tensor]] = None) -> "_lib.NicMlPairs":
+    if len(fp) % 2 or not 2 <= len(fp) // 2 <= _lib.NIC_ML_MAX_LEVELS:
+        raise ValueError(f"2 .. {_lib.NIC_ML_MAX_LEVELS} level pairs")
+    pr = _lib.NicMlPairs()
+    pr.levels = len(fp) // 2
+    for l in range(pr.levels):
+        a, b = fp[2 * l], fp[2 * l + 1]
+        pr.g0[l], pr.g1[l] = a.data_ptr(), b.data_ptr()
+        for ax in range(2):
+            pr.g0_nodes[l][ax] = int(a.shape[-(ax + 1)])
+            pr.g1_nodes[l][ax] = int(b.shape[-(ax + 1)])
+        if grads is not None:
+            pr.g0_grad[l], pr.g1_grad[l] = grads[2 * l].data_ptr(), grads[2 * l + 1].data_ptr()
+    return pr
+
+
+@dataclasses.dataclass
+class MlStepOutput:
+    loss: torch.Tensor                    # device scalar
+    y: Optional[torch.Tensor]
+    grad_fp: List[torch.Tensor]           # one dense fp32 gradient per grid, in fp order
+    grad_mlp: List[torch.Tensor]
+
+
+def _ml_geo_desc(geo: PathGeometry, fp, coord) -> "_lib.NicPathDesc":
+    if geo.dim != 2 or geo.method != 1:
+        raise NotImplementedError("the multi-level mode is 2D")
+    return geo.to_desc(fp[0], fp[1], origins_aligned(geo, coord))
+
+
+@_on_tensor_device
+def fused_ml_forward_backward(geo: PathGeometry, fp: Sequence[torch.Tensor], coord, params, target: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                              want_y: bool = False, grads: Optional[Sequence[torch.Tensor]] = None, mlp_grads: Optional[Sequence[torch.Tensor]] = None,
+                              loss: Optional[torch.Tensor] = None, events=None) -> MlStepOutput:
+    """One multi-level training step in ONE launch (+ the fixed-order reduction of the decoder-gradient records): ``geo`` describes pair 0
+    (``step_number`` = 2^(mip - 2): pair l runs at 4^-l of it), ``fp`` = [G0_0, G1_0, G0_1, G1_1, ..] fp32 grids.  ``grads`` (one fp32 tensor per grid) are
+    ADDED to when given - a whole-image pass walked in chunks - and freshly zeroed otherwise; decoder gradients and the loss are overwritten.
+    Raises ``_lib.Unsupported`` for (levels, C, depth) combinations without a fused kernel (``ml_is_fused``)."""
+    fp = [_lib.require_cuda_f32(g.detach(), f"fp[{i}]") for i, g in enumerate(fp)]
+    L = len(fp) // 2
+    cin = L * (5 * geo.channels + 2 * geo.pe_channels) + 1
+    params = check_mlp([p.detach() for p in params], cin, geo.hidden)
+    dev = fp[0].device
+    org = upload_origins(geo, coord, dev, fp[0], fp[1])
+    target = _lib.require_cuda_f32(target, "target").reshape(-1, 3)
+    if target.shape[0] != geo.n_samples:
+        raise ValueError(f"target has {target.shape[0]} rows, geometry has {geo.n_samples} samples")
+    if geo.noise_mode == NIC_NOISE_TENSOR:
+        noise = _lib.require_cuda_f32(noise, "noise")
+        if tuple(noise.shape) != (geo.n_samples, cin):
+            raise ValueError("noise must be [N, Cin]")
+    if grads is None:
+        grads = [torch.zeros_like(g) for g in fp]
+    if mlp_grads is None:
+        mlp_grads = [torch.empty_like(p) for p in params]
+    if loss is None:
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=dev) if want_y else None
+    d = _ml_geo_desc(geo, fp, coord)
+    d.flags &= ~(_lib.NIC_FLAG_SPLIT_BF16 | _lib.NIC_FLAG_BF16)
+    pr = _ml_pairs(fp, grads)
+    lib = _lib.load()
+    ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(ctypes.byref(d))))
+    m, gs = _mlp_struct(params), _grads_struct(mlp_grads)
+    if events is not None:
+        events[0].record(torch.cuda.current_stream(dev))
+    _lib.check(lib.nic_fused_ml_forward_backward(ctypes.byref(d), ctypes.byref(pr), _lib.ptr(org), ctypes.byref(m),
+                                                 _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(target), _lib.ptr(y), _lib.ptr(loss),
+                                                 ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_ml_forward_backward")
+    if events is not None:
+        events[1].record(torch.cuda.current_stream(dev))
+    return MlStepOutput(loss[0], y, list(grads), list(mlp_grads))
+
+
+@_on_tensor_device
+def fused_ml_forward(geo: PathGeometry, fp: Sequence[torch.Tensor], coord, params) -> torch.Tensor:
+    """forward pass of the multi-level field for the crops at ``coord``: [N, 3]"""
+    fp = [_lib.require_cuda_f32(g.detach(), f"fp[{i}]") for i, g in enumerate(fp)]
+    L = len(fp) // 2
+    cin = L * (5 * geo.channels + 2 * geo.pe_channels) + 1
+    params = check_mlp([p.detach() for p in params], cin, geo.hidden)
+    dev = fp[0].device
+    org = upload_origins(geo, coord, dev, fp[0], fp[1])
+    y = torch.empty(geo.n_samples, 3, dtype=torch.float32, device=dev)
+    d = _ml_geo_desc(geo, fp, coord)
+    d.flags &= ~(_lib.NIC_FLAG_SPLIT_BF16 | _lib.NIC_FLAG_BF16)
+    d.noise_mode = NIC_NOISE_NONE
+    pr = _ml_pairs(fp)
+    m = _mlp_struct(params)
+    _lib.check(_lib.load().nic_fused_ml_forward(ctypes.byref(d), ctypes.byref(pr), _lib.ptr(org), ctypes.byref(m), _lib.ptr(y), _lib.stream_ptr(dev)),
+               "nic_fused_ml_forward")
+    return y
+
+
 class FusedGridMLP(torch.autograd.Function):
     """y[N,3] = decoder(encode(G0, G1) + noise) as ONE differentiable op.  Inputs are the caller's own leaf
     tensors (the reference keeps the grids as raw leaves in a Python list registered in Adam,
