@@ -2,6 +2,7 @@
 import csv, glob, json, os, sys
 tag = sys.argv[1]
 kern = sys.argv[2] if len(sys.argv) > 2 else "fused_train16_kernel"     # the dominant kernel of the default bench (substring of its name)
+# argv[3]: the key of profiles/issue.json = bench.py's kernel_name() of the timed configuration (default: the substring)
 update_traffic = kern.startswith("fused_train16")                       # profiles/traffic.json is the headline kernel's
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
@@ -41,4 +42,14 @@ traffic = {"fused_kernel_bytes_per_launch": int(2 * vals["FETCH_SIZE"] * 1024 + 
                    "outside the calibrated pattern, so this is an upper bound), WRITE_SIZE as is (exact for float atomics)."}
 traffic["note"] = traffic["note"].replace("fused_train16_kernel (Layout<1>, MODE_TRAIN_MSE)", kern)
 json.dump(traffic, open(os.path.join(dst, "traffic.json" if update_traffic else f"{tag}_traffic.json"), "w"), indent=1)
-print(line[:300]); print("\n".join(out[:12])); print(traffic["fused_kernel_bytes_per_launch"])
+# what binds the kernel: per-SIMD busy fractions (GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles; 256 CUs x 4 SIMDs; a wave instruction holds the vector ALU 4 cycles)
+simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+issue = {"valu_busy": round(4.0 * vals["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4), "mfma_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
+         "wait": round(vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], 4), "lds_conflict": round(vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"], 4),
+         "insts_valu_per_mfma": round(vals["SQ_INSTS_VALU"] / max(vals["SQ_INSTS_MFMA"], 1.0), 2), "waves": int(vals["SQ_WAVES"]), "pmc": f"profiles/{tag}_pmc.csv"}
+ip = os.path.join(dst, "issue.json")
+allrec = json.load(open(ip)) if os.path.exists(ip) else {}
+kname = [l for l in open(stats).read().split("\n") if kern in l]
+allrec[sys.argv[3] if len(sys.argv) > 3 else kern] = issue
+json.dump(allrec, open(ip, "w"), indent=1, sort_keys=True)
+print(line[:300]); print("\n".join(out[:12])); print(traffic["fused_kernel_bytes_per_launch"]); print(issue)

@@ -184,7 +184,30 @@ def pct(xs):
             "p90": round(float(np.percentile(xs, 90)), 4), "min": round(float(xs.min()), 4), "mean": round(float(xs.mean()), 4)}
 
 
-def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic=None, stats=None, grid_bytes=4):
+ISSUE_SOURCE = "profiles/issue.json"
+
+
+def issue_record(kernel):
+    """What actually binds these kernels: per-SIMD busy fractions from the committed rocprofv3 --pmc passes of the SAME kernel
+    (profiles/issue.json, written by ab/collect_profiles.py; not measured in this run): vector ALU (4 cycles per wave instruction), matrix pipe,
+    the share of wave-cycles spent waiting, the share of LDS cycles lost to bank conflicts."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "issue.json"))).get(kernel)
+    except Exception:
+        rec = None
+    if rec is None:
+        return None
+    return {**rec, "issue_source": ISSUE_SOURCE + " (rocprofv3 --pmc passes of this kernel, committed with the tree; not measured in this run)"}
+
+
+def cell_granular_bytes(dim, method, n_launch, grid_nodes, param_bytes=4, target_bytes=12, channels=12):
+    """HBM bytes of one launch if every touched grid node is read once and its gradient read-modify-written once (what the cell-major kernels do:
+    a G0 cell's 16 / 64 samples share their corners) + the targets: the bound the element-granular figure of SURVEY 8d overstates by the reuse"""
+    nodes = int(sum(grid_nodes))
+    return channels * nodes * (param_bytes + 8) + n_launch * target_bytes
+
+
+def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic=None, stats=None, grid_bytes=4, grid_nodes=None):
     """SURVEY 8d figures x the samples one launch processes / the kernel's launch duration.  The binding roofline: fp32 products -> the
     fp32 matrix pipe (157.3 TFLOP/s / 53 760 = 2.9 Gpx/s against HBM 8 TB/s / 1 164 B = 6.9 Gpx/s); bf16-pipe products (split: three
     MFMAs per product; plain: one) -> the algorithmic-HBM figure.  `frac_bf16_storage` is the same speed priced at the bytes
@@ -199,6 +222,15 @@ def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic
         common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of this tree's split kernel, profiles/r03_z_pmc.csv; not measured in this run)"
     if stats is not None:
         common["stats"] = stats
+    iss = issue_record(common["kernel"])
+    if iss is not None:
+        common["issue"] = iss
+    if grid_nodes is not None:
+        cb = cell_granular_bytes(dim, method, n_launch, grid_nodes, grid_bytes)
+        cg = cb / (kern_ms * 1e-3) / 1e9
+        common["hbm_cell_granular"] = {"bytes_per_launch": cb, "achieved": round(cg, 1), "unit": "GB/s", "frac": round(cg / PEAK_HBM_GBS, 4),
+                                       "note": "every touched node read once + its gradient read-modify-written once + targets: the traffic a cell-major kernel "
+                                               "needs; `frac` (element-granular, SURVEY 8d) prices every sample's 8 corner reads and 16 gradient updates separately"}
     hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
            "frac_bf16_storage": round(byt16 * n_launch / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "bytes_per_sample_bf16_storage": byt16}
     if precision == "f32":
@@ -491,11 +523,12 @@ def run_sharded(args, rank, world, dev):
         }
         if psnr is not None:
             res["config"]["psnr_db_after_these_steps"] = round(psnr, 3)
+        nodes = [int(g[0].numel()) for g in fit.master]
         res["roofline"] = roofline_record(dim, method, args.precision, fit.nl, kern_ms, n_mine, traffic,
-                                          {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})}, gb)
+                                          {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})}, gb, nodes)
         for other, xs in extra.items():
             # another arithmetic mode on the same inputs in the same run: its median launch time carries the record
-            r = roofline_record(dim, method, other, fit.nl, float(np.median(xs)), n_mine, None, {"stat_leg": pct(xs)}, gb)
+            r = roofline_record(dim, method, other, fit.nl, float(np.median(xs)), n_mine, None, {"stat_leg": pct(xs)}, gb, nodes)
             r["m%s_s_kernel_only" % ("vox" if video else "pix")] = round(n_mine / float(np.median(xs)) / 1e3, 1)
             if other == "bf16":
                 r["parity"] = "against the precision-emulating oracle at 1e-3 (tests/test_gpu_bf16.py); ~5e-3 from fp32 arithmetic"
@@ -589,7 +622,7 @@ def main():
     ap.add_argument("--target", choices=["tensor", "image"], default="tensor",
                     help="4k: tensor = resident fp32 [N,3] targets (the reference's crop stack, built once); image = targets read from the "
                          "resident RGBX uint8 image inside the step (a third of the bytes, one dword load per sample)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N > 1.  weak: the whole domain per RANK and step; strong: ONE pass over the domain per step, split N ways")
     ap.add_argument("--shard", choices=["stripes", "replicated"], default="stripes",
                     help="N > 1.  stripes: every rank owns a stripe of the last sample axis (a contiguous block of grid node rows); the step "

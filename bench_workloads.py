@@ -259,15 +259,20 @@ def _run_fits8(args, dev):
                          "frac": round(byt * res[best]["mpix_s"] * 1e6 / 1e9 / PEAK_HBM_GBS, 4), "traffic": None}}
 
 
-def _run_multilevel(args, dev, levels=5, n_linear=5, chunk=(1024, 540)):
-    """one step = one pass over every pixel of a 3840 x 2160 image in chunks (gradients accumulate, one Adam launch at the end)"""
+def _run_multilevel(args, dev, levels=5, channels=4, n_linear=3, layerwise=False, chunk=(1024, 540)):
+    """one step = one pass over every pixel of a 3840 x 2160 image + one Adam launch over all 2 L grids and the decoder.  Fused route (the default where a
+    kernel exists, fused.ml_is_fused): ONE launch for the whole pass - gathers of every pair, in-kernel noise, plain-bf16 decoder, loss, backward, one gradient
+    flush per touched cell and pair (csrc/fused_q16.hpp::QML).  ``layerwise``: round 3's composition of nic_encode x L + the general decoder, in chunks."""
     from neural_image_compression_v2_amd.multilevel import MultiLevelField
     H, W = 2160, 3840
-    f = MultiLevelField((H, W), levels, hidden=64, n_linear=n_linear, device=dev, seed=0)
+    f = MultiLevelField((H, W), levels, channels=channels, hidden=64, n_linear=n_linear, device=dev, seed=0, fused_step=False if layerwise else None)
     tgt = torch.rand(H, W, 3, device=dev)
     chunks = [(x0, y0) for x0 in range(0, H, chunk[1]) for y0 in range(0, W, chunk[0])]
+    flat_t = tgt.reshape(-1, 3)
 
     def step():
+        if f.fused_step:
+            return f.train_step([[0, 0]], (H, W), flat_t, noise=True)
         tot = None
         for k, (x0, y0) in enumerate(chunks):
             ext = (min(chunk[1], H - x0), min(chunk[0], W - y0))
@@ -285,20 +290,23 @@ def _run_multilevel(args, dev, levels=5, n_linear=5, chunk=(1024, 540)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     px = H * W
-    C, P = 12, 6
+    C, P = channels, 6
     byt = levels * (8 * C * 4 + 2 * 8 * C * 4) + 3 * 4                      # SURVEY 8d's extended-mode formula: L pairs x (K0 + K1) C x (e_param + 2 e_grad) + target
     flop = 6 * (f.cin * 64 + (n_linear - 2) * 64 * 64 + 3 * 64)
-    return {"metric": "Mpixels/sec train-step, multi-level extension (layer-wise kernels)", "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"3840x2160 RGB fit, every pixel once per step, {levels} level pairs ({2 * levels} grids "
-                                   f"{[list(g.shape) for g in f.fp]}) concatenated: Cin {f.cin}, {n_linear}xLinear(64) decoder, torch.rand noise, MSE, "
-                                   f"{len(chunks)} chunks of {chunk[1]}x{chunk[0]} px, Adam + clamp", "samples_per_step": px, "final_loss": round(float(loss), 6),
-                       "parameters": int(sum(g.numel() for g in f.fp))},
-            "roofline": {"bound": "hbm", "achieved": round(byt * px / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(byt * px / dt / 1e9 / PEAK_HBM_GBS, 4),
-                         "traffic": None, "bytes_per_sample": byt, "flop_per_sample": flop,
-                         "note": "algorithmic bytes of the extended mode; this route MATERIALISES the [N, Cin] input, its gradient and every activation "
-                                 f"(~ {4 * (3 * f.cin + 4 * (n_linear - 1) * 64)} B per sample of real traffic): it is the unfused composition, not a fused kernel"}}
+    route = "fused (one launch per step: nic_fused_ml_forward_backward, plain-bf16 products, in-kernel noise)" if f.fused_step else \
+            f"layer-wise (nic_encode x L + general decoder, torch.rand noise, {len(chunks)} chunks of {chunk[1]}x{chunk[0]} px)"
+    rec = {"metric": "Mpixels/sec train-step, multi-level extension", "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 operands, f32 accumulate" if f.fused_step else "f32", "data": "synthetic",
+           "config": {"workload": f"3840x2160 RGB fit, every pixel once per step, {levels} level pairs of {C} channels ({2 * levels} grids "
+                                  f"{[list(g.shape) for g in f.fp]}) concatenated: Cin {f.cin}, {n_linear}xLinear(64) decoder, noise, MSE, Adam + clamp; route: {route}",
+                      "samples_per_step": px, "final_loss": round(float(loss), 6), "parameters": int(sum(g.numel() for g in f.fp)), "fused": bool(f.fused_step)},
+           "roofline": {"bound": "hbm", "achieved": round(byt * px / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(byt * px / dt / 1e9 / PEAK_HBM_GBS, 4),
+                        "traffic": None, "bytes_per_sample": byt, "flop_per_sample": flop,
+                        "note": "algorithmic bytes of the extended mode (element-granular, no reuse); whole step by wall clock, optimiser included"}}
+    if not f.fused_step:
+        rec["roofline"]["note"] += f"; this route MATERIALISES the [N, Cin] input, its gradient and every activation (~ {4 * (3 * f.cin + 4 * (n_linear - 1) * 64)} B per sample of real traffic)"
+    return rec
 
 
 def run(args):
@@ -326,7 +334,13 @@ def run(args):
     elif w == "fits8":
         recs.append(_run_fits8(args, dev))
     elif w == "multilevel":
-        recs.append(_run_multilevel(args, dev))
+        # the fused kernels: 5 pairs x 4 channels (Cin 161) with the reference's 3-Linear decoder - what fits the LDS at L = 5 -, 3 pairs
+        # with the north star's 5-Linear decoder, 3 pairs x 12 channels; then round 3's layer-wise composition at 5 x 12 (Cin 361, no fused kernel) for reference
+        recs.append(_run_multilevel(args, dev, 5, 4, 3))
+        recs.append(_run_multilevel(args, dev, 3, 4, 5))
+        recs.append(_run_multilevel(args, dev, 3, 12, 3))
+        if getattr(args, "ml_layerwise", False):
+            recs.append(_run_multilevel(args, dev, 5, 12, 5, layerwise=True))
     else:
         raise SystemExit(f"unknown workload {w}")
     for r in recs:

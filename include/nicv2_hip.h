@@ -87,6 +87,9 @@ typedef struct nic_path_desc {
                               * dy rows (N = num_crops * passes * n_per_crop) - the same result as listing the crop `passes` times, but
                               * a cell's gradients are summed over all passes before they go to memory (stripe-sharded multi-GPU steps).
                               * Every other entry point: 0 or 1. */
+    int32_t dz_scale_log2;   /* NIC_FLAG_FP16 only: dZ is carried as 2^dz_scale_log2 x dZ.  0: nic_fused_forward_backward / _img / _img_dev choose it from
+                              * loss_scale (2 loss_scale 2^k in [4, 8)); nic_fused_backward_dy takes 2^0 - pass the exponent that brings the incoming
+                              * dY to O(1) (a mean-squared-error dY is 2 (y - t) / (3 N): k = round(log2(3 N)) + 1) */
     int32_t max_workgroups;  /* 0: the launch may fill the chip (one persistent workgroup per CU, two for inference).  n > 0: at most n
                               * workgroups (rounded down to a multiple of 8, at least 8): independent fits launched on separate
                               * streams (BASELINE config 5) then share the CUs side by side instead of queueing behind each other's
@@ -126,6 +129,13 @@ typedef struct nic_path_desc {
  * n_linear 3 or 5, fp32 or 16-bit grid storage; 8 waves x 16 samples, two waves per SIMD.  Takes precedence over NIC_FLAG_SPLIT_BF16.
  * Results are checked against the precision-emulating oracle at 1e-3 (outputs) and stay within ~1e-2 of the fp32 arithmetic. */
 #define NIC_FLAG_BF16 64
+/* PLAIN fp16 matrix products: NIC_FLAG_BF16's kernels, rounding points and entry points with IEEE half operands instead of bfloat16 (the reference's own
+ * 16-bit type: FP_NUM_DTYPE / MLP_NUM_DTYPE = 16 map to torch.float16, utils.py:301-313; BASELINE config 3's "fp16"): v_mfma_f32_16x16x32_f16 runs at the
+ * bf16 rate with 11 significant bits instead of 8 - outputs ~2e-5 and gradients ~1e-3 from the fp32 arithmetic, checked against the fp32 oracle directly.
+ * dZ of a mean over millions of samples is far below the half range (2 loss_scale ~ 1e-7), so the kernel carries 2^k dZ and multiplies every sum of dZ
+ * products by 2^-k where it leaves the kernel (exact): k = nic_path_desc.dz_scale_log2, or - 0 - chosen from loss_scale by the MSE entry points.  Default
+ * channel counts; takes precedence over NIC_FLAG_BF16 and NIC_FLAG_SPLIT_BF16. */
+#define NIC_FLAG_FP16 128
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
  * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three

@@ -274,6 +274,24 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.noise.off_lo = (uint32_t)d->noise_offset; p.noise.off_hi = (uint32_t)(d->noise_offset >> 32);
     p.noise.scale = ldexpf(1.0f, -d->num_bits);
     p.grad_scale = 2.0f * d->loss_scale;
+    p.f16 = 0;
+    p.dz_scale = p.dz_unscale = 1.0f;
+}
+// NIC_FLAG_FP16: the loss scale of dZ (FusedParams::dz_scale).  auto_from_loss: 2^k with 2 loss_scale 2^k in [4, 8) - the output layer's dZ is then at most
+// ~ 2 and everything behind it stays O(1): far from both ends of the half range
+void set_f16(FusedParams& p, const nic_path_desc* d, bool auto_from_loss) {
+    p.f16 = 1;
+    int k = d->dz_scale_log2;
+    if (k == 0 && auto_from_loss && p.grad_scale > 0.f) {
+        int e = 0;
+        frexpf(p.grad_scale, &e);                                     // grad_scale = m 2^e, m in [0.5, 1)
+        k = 3 - e;
+        if (k < 0) k = 0;
+    }
+    if (k > 60) k = 60;
+    if (k < -60) k = -60;
+    p.dz_scale = ldexpf(1.0f, k);
+    p.dz_unscale = ldexpf(1.0f, -k);
 }
 int mlp_depth(const nic_mlp* m) { return m->n_linear == 0 ? 3 : m->n_linear; }
 bool depth_unsupported(const nic_mlp* m) { const int n = mlp_depth(m); return n != 3 && n != 5 && n >= 2 && n <= NIC_MAX_LINEAR; }
@@ -396,8 +414,10 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         if (img->is_u8 && !(img->den > 0.f)) return NIC_E_ARG;
     }
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
-    const bool q16 = (d->flags & NIC_FLAG_BF16) != 0;                  // plain-bf16 products: every layout on the quarter kernels
+    const bool f16 = (d->flags & NIC_FLAG_FP16) != 0;                  // .. on IEEE half operands
+    const bool q16 = (d->flags & NIC_FLAG_BF16) != 0 || f16;           // plain 16-bit products: every layout on the quarter kernels
     if (q16 && (d->flags & NIC_FLAG_GRID_BF16) && (d->flags & NIC_FLAG_GRID_FP16)) return NIC_E_ARG;
+    if (f16 && !cp_default(d)) return NIC_E_UNSUPPORTED;
     bool mlpn = false;
     if (!q16) {
         rc = use_mlpn(layout, d, mlp, false, mlpn);
@@ -426,6 +446,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
         p.timg_rcp = 1.0f / p.timg_den;
     }
     p.grid_kind = grid_kind_of(d);
+    if (f16) set_f16(p, d, target != nullptr || img != nullptr);
     if (p.grid_kind != 0 && !(mlpn || t16 || q16)) return NIC_E_UNSUPPORTED;
     if (step_dev != nullptr && !(t16 || q16)) return NIC_E_UNSUPPORTED;                // the device-side step: the two-waves-per-SIMD kernels
     p.step_dev = step_dev;

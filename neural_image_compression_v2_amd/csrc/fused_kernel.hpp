@@ -127,6 +127,10 @@ struct FusedParams {
     int64_t seg_split;     // macro-tiles [0, seg_split) run in 2^rg0_log2 groups of rounds (fused_train16: whole units), the rest in 2^rg_log2 groups; 0 = one segment
     int rg0_log2;
     float grad_scale;      // 2 * loss_scale
+    int f16;               // plain 16-bit products on IEEE half operands (NIC_FLAG_FP16) instead of bfloat16
+    float dz_scale, dz_unscale;   // fp16 products (NIC_FLAG_FP16): dZ is carried as dz_scale x dZ, dz_scale = 2^k chosen by the host so that 2 loss_scale 2^k is O(1)
+                           // (gradients of a mean over millions of samples are far below the fp16 range); every sum of dZ products is multiplied by
+                           // dz_unscale = 2^-k where it leaves the kernel (records, grid-gradient atomics): exact.  1 / 1 in every other mode
     // hipGraph-captured training loops (nic_fused_forward_backward_img_dev): the step number lives in DEVICE memory and is added to the
     // noise offset at kernel start, so one captured launch serves every step (fused_train16 / fused_q16 kernels; null everywhere else)
     const int64_t* step_dev;

@@ -202,25 +202,58 @@ struct LdsQ {
     static constexpr int REC = REC_WAVE + 8 * WTAIL;
 };
 
-// two fp32 values -> a bf16 pair (round to nearest even: v_cvt_pk_bf16_f32).  (Measured and dropped: the rounding in integer arithmetic - bits + 0x8000 per
-// value, one v_perm_b32 per pair - is 3 instructions for 1 and cost the 5-layer 4K launch +5.8 %: this kernel is bound by instruction ISSUE, ~ 4 cycles of
-// the SIMD per vector instruction of any kind.  __builtin_amdgcn_perm on the two lanes of a packed-fp32 result is also MISCOMPILED by ROCm 7.2 - both
-// operands become the low lane.)
+// ---- the 16-bit operand type of the products: bfloat16 (NIC_FLAG_BF16) or IEEE half (NIC_FLAG_FP16: the reference's own 16-bit type, utils.py:301-313, and
+// BASELINE config 3's "fp16"; v_mfma_f32_*_f16 run at the bf16 rate with 3 more mantissa bits).  Fragments are carried as bf16x8 bit containers either way.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// two fp32 values -> a 16-bit pair, round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).  (Measured and dropped: the bf16 rounding in integer
+// arithmetic - bits + 0x8000 per value, one v_perm_b32 per pair - is 3 instructions for 1 and cost the 5-layer 4K launch +5.8 %: this kernel is bound by
+// instruction ISSUE, ~ 4 cycles of the SIMD per vector instruction of any kind.)
+template <bool F16>
 __device__ __forceinline__ uint32_t pk16(float lo, float hi) {
     const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-__device__ __forceinline__ __bf16 bf16_1(float v) { return (__bf16)v; }
-// 8 fp32 values -> one bf16 fragment
+template <bool F16>
+__device__ __forceinline__ __bf16 to16(float v) {                       // one value (bit container)
+    if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
+    else return (__bf16)v;
+}
+// 8 fp32 values -> one fragment
+template <bool F16>
 __device__ __forceinline__ bf16x8 cvt8(const float (&x)[8]) {
     u32x4 hp;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) hp[i] = pk16(x[2 * i], x[2 * i + 1]);
+    for (int i = 0; i < 4; ++i) hp[i] = pk16<F16>(x[2 * i], x[2 * i + 1]);
     return __builtin_bit_cast(bf16x8, hp);
 }
+template <bool F16>
 __device__ __forceinline__ bf16x8 cvt_pair(const f32x4& a, const f32x4& b) {        // registers of row tiles 2s, 2s + 1 = k-step s
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return cvt8(x);
+    return cvt8<F16>(x);
+}
+// the matrix instructions of either operand type
+template <bool F16>
+__device__ __forceinline__ f32x4 mm16(bf16x8 a, bf16x8 b, f32x4 c) {                // 16x16x32
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else return mfma16_bf(a, b, c);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mm32(bf16x8 a, bf16x8 b, f32x16 c) {              // 32x32x16
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else return mfma_bf(a, b, c);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mm4(s16x4 a, s16x4 b, f32x4 c) {                   // 4x4x4
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+    else return mfma4_bf(a, b, c);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mm16h(s16x4 a, s16x4 b, f32x4 c) {                 // 16x16x16
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+    else return mfma16h_bf(a, b, c);
 }
 // Materialise a packed fragment where it is written.  Left alone, the compiler SINKS the tail of a GELU derivative (z phi(z) + Phi(z), the rounding, the
 // packing) from the forward pass down to its use in the backward pass and keeps three fp32 intermediates per value alive across the whole round instead
@@ -231,12 +264,18 @@ __device__ __forceinline__ void pin(bf16x8& f) {
     asm volatile("" : "+v"(t));
     f = __builtin_bit_cast(bf16x8, t);
 }
-// the fp32 values of a packed fragment: elements 0..3 (lo = false) or 4..7 (lo = true)
+// the fp32 values of a packed fragment: elements 0..3 (hi4 = false) or 4..7 (hi4 = true)
+template <bool F16>
 __device__ __forceinline__ f32x4 unpack4(const bf16x8& f, bool hi4) {
     const u32x4 w = __builtin_bit_cast(u32x4, f);
     const uint32_t a = hi4 ? w[2] : w[0], b = hi4 ? w[3] : w[1];
-    return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u), __builtin_bit_cast(float, b << 16),
-                 __builtin_bit_cast(float, b & 0xFFFF0000u)};
+    if constexpr (F16) {
+        const h16x2 ha = __builtin_bit_cast(h16x2, a), hb = __builtin_bit_cast(h16x2, b);
+        return f32x4{(float)ha[0], (float)ha[1], (float)hb[0], (float)hb[1]};
+    } else {
+        return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xFFFF0000u), __builtin_bit_cast(float, b << 16),
+                     __builtin_bit_cast(float, b & 0xFFFF0000u)};
+    }
 }
 // GELU + derivative of one row tile (four values per lane) in the form the plain 16-bit modes use (nic_device.hpp::gelu_sig4); 0 = the exact-erf form
 #ifndef NIC_Q16_GELU
@@ -249,7 +288,7 @@ __device__ __forceinline__ void gelu_q(const f32x4& z, f32x4& a, f32x4& d) {
 // (Measured and dropped: the GELU derivatives kept as the fp32 values they are instead of packed bf16 pairs - 16 registers per hidden layer, no conversion,
 // no unpacking: 5 layers 2.128 -> 2.125 ms, 3 layers 1.258 -> 1.288: the instructions it saves are paid back in register moves.)
 // acc[t] += A_t x B for the NT row tiles of one k-step, A fragments fetched PF tiles ahead
-template <int NT, bool ZERO = false, int PFQ = NIC_T16_PF, class LoadA>
+template <int NT, bool ZERO = false, int PFQ = NIC_T16_PF, bool F16 = false, class LoadA>
 __device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, LoadA&& load_a) {
     constexpr int PF = PFQ < NT ? PFQ : NT;
     bf16x8 af[PF];
@@ -257,7 +296,7 @@ __device__ __forceinline__ void kstep_b(f32x4 (&acc)[NT], const bf16x8& bf, Load
     for (int t = 0; t < PF; ++t) af[t] = load_a(t);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        acc[t] = mfma16_bf(af[t % PF], bf, ZERO ? f32x4(0.f) : acc[t]);
+        acc[t] = mm16<F16>(af[t % PF], bf, ZERO ? f32x4(0.f) : acc[t]);
         if (t + PF < NT) af[t % PF] = load_a(t + PF);
     }
 }
@@ -442,7 +481,7 @@ __device__ __forceinline__ float seg_sum16(float v, const bool (&same)[4], int l
 }
 template <class Q, int NDX>
 __device__ __forceinline__ void flush_ml(const FusedParams& p, const uint32_t (&off0)[Q::LEVELS], const uint32_t (&off1)[Q::LEVELS], const f32x4 (&dxacc)[NDX],
-                                         const float (&g1s)[QInfo<Q>::NG1V], int ln) {
+                                         const float (&g1s)[QInfo<Q>::NG1V], int ln, float us = 1.0f) {
     const int n16 = ln & 15, g = ln >> 4;
 #pragma unroll
     for (int l = 0; l < Q::LEVELS; ++l) {
@@ -472,7 +511,7 @@ __device__ __forceinline__ void flush_ml(const FusedParams& p, const uint32_t (&
                     const uint32_t pb = (uint32_t)a.plane * 4u;
                     char* gbase = reinterpret_cast<char*>(p.ml[l].g0_grad);
 #pragma unroll
-                    for (int c = 0; c < Q::C; ++c, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[c]);
+                    for (int c = 0; c < Q::C; ++c, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[c] * us);
                 }
             } else {
                 const GridView& b = p.ml[l].g1;
@@ -490,7 +529,7 @@ __device__ __forceinline__ void flush_ml(const FusedParams& p, const uint32_t (&
                     for (int q = 0; q < 4; ++q) {
                         uint32_t ob = (key + (uint32_t)b.at(q >> 1, q & 1, 0) + (uint32_t)(Q::GQ * g) * (uint32_t)b.plane) * 4u;
 #pragma unroll
-                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[q * Q::GQ + cc]);
+                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb) atomicAdd(reinterpret_cast<float*>(gbase + ob), v[q * Q::GQ + cc] * us);
                     }
                 }
             }
@@ -718,7 +757,7 @@ __device__ __forceinline__ void preadd_y_q(f32x4 (&dxacc)[NA], uint32_t off0, ui
 #else
 #define NIC_Q16_ATTR
 #endif
-template <class Q, int MODE, int NL>
+template <class Q, int MODE, int NL, bool F16 = false>
 __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams p) {
     using S = LdsQ<Q, NL>;
     using I = QInfo<Q>;
@@ -786,7 +825,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             const float v = p.W[0][o * Q::CIN + (ch >= 0 ? ch : 0)];
             return ch >= 0 ? v : 0.f;                                   // the constant-one column stays zero: b1 is added in fp32
         },
-        [&](int idx, float v) { sm[S::OFF_W1 + idx] = bf16_1(v); });
+        [&](int idx, float v) { sm[S::OFF_W1 + idx] = to16<F16>(v); });
 #ifdef NIC_STAMPS
     unsigned long long stamp_t1, stamp_t2;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t1)::"memory");
@@ -800,14 +839,14 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 const float v = Wk[o * kH + hid16(ps < kH ? ps : 0)];
                 return ps < kH ? v : 0.f;
             },
-            [&](int idx, float v) { sm[S::OFF_WH + k * S::WSZ + idx] = bf16_1(v); });
+            [&](int idx, float v) { sm[S::OFF_WH + k * S::WSZ + idx] = to16<F16>(v); });
     }
     stage_all<4 * LDH, 512>(tid,
         [&](int idx) {
             const int c = idx / LDH, ps = idx - c * LDH;
             return (c < 3 && ps < kH) ? p.W[NL - 1][c * kH + hid16(ps)] : 0.f;
         },
-        [&](int idx, float v) { sm[S::OFF_WO + idx] = bf16_1(v); });
+        [&](int idx, float v) { sm[S::OFF_WO + idx] = to16<F16>(v); });
 #ifdef NIC_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t2)::"memory");
 #endif
@@ -1007,15 +1046,15 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int s = 0; s < KF; ++s) {
                         const float xv[8] = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3], xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6], xs[8 * s + 7]};
-                        const bf16x8 bf = cvt8(xv);
+                        const bf16x8 bf = cvt8<F16>(xv);
                         if (TRAIN) st_frag(&x_st[32 * s], bf);
-                        kstep_b<4, false, KPF>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
+                        kstep_b<4, false, KPF, F16>(z, bf, [&](int t) { return ld_frag(&w1_row[16 * t * LD1 + 32 * s]); });
                     }
                     if constexpr (HALF) {   // slots 8 KF .. 8 KF + 3: compact columns 32 KF + 4 g + j
                         lds_cbf* const w1_row2 = opaque((lds_cbf*)(sm + S::OFF_W1 + 32 * KF + (LOFF ? lo_r1 - 4 * g : n16 * LD1 + 4 * g)));
                         lds_bf* const x_st2 = LOFF ? opaque(img0 + 32 * KF + lo_rX - 4 * g) : opaque(imgw + n16 * LDX + 32 * KF + 4 * g);
                         const float xv[8] = {xs[8 * KF], xs[8 * KF + 1], xs[8 * KF + 2], xs[8 * KF + 3], 0.f, 0.f, 0.f, 0.f};
-                        const bf16x8 bf = cvt8(xv);
+                        const bf16x8 bf = cvt8<F16>(xv);
                         const s16x8 bh = __builtin_bit_cast(s16x8, bf);
                         if (TRAIN) *reinterpret_cast<lds_s16x4*>(x_st2) = s16x4{bh[0], bh[1], bh[2], bh[3]};
                         if constexpr (NIC_Q16_HALF16 == 1 || (NIC_Q16_HALF16 == 2 && NL == 5)) {
@@ -1023,9 +1062,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                             // (measured: 5 layers 2.365 -> 2.348 ms; 3 layers and method 4 unchanged - with SLP vectorisation still on it LOST 1.4 % there)
                             const s16x4 bq = {bh[0], bh[1], bh[2], bh[3]};
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) z[t] = mfma16h_bf(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]), bq, z[t]);
+                            for (int t = 0; t < 4; ++t) z[t] = mm16h<F16>(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1]), bq, z[t]);
                         } else {
-                            kstep_b<4, false, KPF>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
+                            kstep_b<4, false, KPF, F16>(z, bf, [&](int t) { return half_frag(*reinterpret_cast<lds_cs16x4*>(&w1_row2[16 * t * LD1])); });
                         }
                     }
                 }
@@ -1037,8 +1076,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     f32x4 a4[2], d4[2];
                     gelu_q(z[2 * s], a4[0], d4[0]);
                     gelu_q(z[2 * s + 1], a4[1], d4[1]);
-                    af[s] = cvt_pair(a4[0], a4[1]);
-                    dpk[0][s] = cvt_pair(d4[0], d4[1]);
+                    af[s] = cvt_pair<F16>(a4[0], a4[1]);
+                    dpk[0][s] = cvt_pair<F16>(d4[0], d4[1]);
                     if (PIN) pin(dpk[0][s]);
                 }
 #pragma unroll
@@ -1049,15 +1088,15 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         if (TRAIN) st_frag(&a_st[32 * s], af[s]);
-                        kstep_b<4, false, KPF>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
+                        kstep_b<4, false, KPF, F16>(z, af[s], [&](int t) { return ld_frag(&w_row[S::OFF_WH + k * S::WSZ + 16 * t * LDH + 32 * s]); });
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         f32x4 a4[2], d4[2];
                         gelu_q(z[2 * s], a4[0], d4[0]);
                         gelu_q(z[2 * s + 1], a4[1], d4[1]);
-                        af[s] = cvt_pair(a4[0], a4[1]);
-                        dpk[k + 1][s] = cvt_pair(d4[0], d4[1]);
+                        af[s] = cvt_pair<F16>(a4[0], a4[1]);
+                        dpk[k + 1][s] = cvt_pair<F16>(d4[0], d4[1]);
                         if (PIN) pin(dpk[k + 1][s]);
                     }
                 }
@@ -1071,7 +1110,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         if (TRAIN) st_frag(&dz_st[32 * s], af[s]);
-                        z3 = mfma16_bf(ld_frag(&wo_row[32 * s]), af[s], s == 0 ? f32x4(0.f) : z3);
+                        z3 = mm16<F16>(ld_frag(&wo_row[32 * s]), af[s], s == 0 ? f32x4(0.f) : z3);
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[(NH + 1) * kH + c]);
@@ -1095,9 +1134,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     if (MODE == MODE_TRAIN_MSE || MODE == MODE_TRAIN_IMG) {
                         const float diff = own ? yv[c] - tgt[c] : 0.f;
                         accLoss += diff * diff;
-                        gr = p.grad_scale * diff;
+                        gr = (F16 ? p.grad_scale * p.dz_scale : p.grad_scale) * diff;       // fp16 products: dZ is carried as 2^k dZ (FusedParams::dz_scale)
                     } else {
-                        gr = own ? tgt[c] : 0.f;
+                        gr = own ? (F16 ? tgt[c] * p.dz_scale : tgt[c]) : 0.f;
                     }
                     dz3[c] = gr * yv[c] * (1.0f - yv[c]);
                     accBO[c] += dz3[c];
@@ -1105,7 +1144,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 if (g == 0) {
                     lds_bf* const d3_st = opaque(imgw + S::OFF_D3 + 4 * (n16 & 3) + (n16 >> 2));
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) d3_st[c * 16] = bf16_1(dz3[c]);
+                    for (int c = 0; c < 3; ++c) d3_st[c * 16] = to16<F16>(dz3[c]);
                 }
             }
             wave_lds_fence();
@@ -1125,17 +1164,17 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         ah[r] = *reinterpret_cast<lds_cs16x4*>(&d3_a44[4 * r]);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accWOq = mfma4_bf(ah[r], bh[r], accWOq);
+                    for (int r = 0; r < 4; ++r) accWOq = mm4<F16>(ah[r], bh[r], accWOq);
                 }
                 {   // dA_last = W_out^T dZ_out (k = c: quarter 0 carries dZ_out in elements 0..2), dZ = dA * gelu'
                     lds_cbf* const wo_tr = opaque((lds_cbf*)(sm + S::OFF_WO + q4 * LDH + 8 * p4));
                     const float dzv[8] = {dz3[0], dz3[1], dz3[2], 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const bf16x8 bf = cvt8(dzv);
+                    const bf16x8 bf = cvt8<F16>(dzv);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const s16x4 a = tr4(&wo_tr[32 * (t >> 1) + 4 * (t & 1)]);        // rows c = 0..3; the k = 4..31 part meets zeros
-                        const f32x4 dl = mfma16_bf(join8(a, a), bf, f32x4(0.f));
-                        dzc[t] = dl * unpack4(dpk[NH][t >> 1], t & 1);
+                        const f32x4 dl = mm16<F16>(join8(a, a), bf, f32x4(0.f));
+                        dzc[t] = dl * unpack4<F16>(dpk[NH][t >> 1], t & 1);
                     }
                 }
             }
@@ -1154,25 +1193,25 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     lds_bf* const dz_st = LOFF ? opaque(img0 + DZO + lo_rZ) : opaque(imgw + DZO + n16 * LDZ + 8 * g);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
+                        const bf16x8 bf = cvt_pair<F16>(dzc[2 * s], dzc[2 * s + 1]);
                         st_frag(&dz_st[32 * s], bf);
                         auto la = [&](int t) {
                             const int co = 32 * (t >> 1) + 4 * (t & 1);
                             return join8(tr4(&wh_tr[32 * s * LDH + co]), tr4(&wh_tr[(32 * s + 16) * LDH + co]));
                         };
-                        if (s == 0) kstep_b<4, true, KPF>(acc, bf, la);
-                        else kstep_b<4, false, KPF>(acc, bf, la);
+                        if (s == 0) kstep_b<4, true, KPF, F16>(acc, bf, la);
+                        else kstep_b<4, false, KPF, F16>(acc, bf, la);
                     }
                     wave_lds_fence();
                     {   // db[pos = lane] += sum_n dZ[pos][n]: 4x4x4 MFMAs against a block of ones
                         lds_cbf* const dz_b44 = LOFF ? opaque((lds_cbf*)(img0 + DZO + lo_b44)) : opaque((lds_cbf*)(imgw + DZO + 4 * q4 * LDZ + 16 * g + 4 * p4));
-                        const short one = (ln & 3) == k ? (short)0x3F80 : (short)0;      // A[i][.] = 1 for output row i = k only
+                        const short one = (ln & 3) == k ? (short)(F16 ? 0x3C00 : 0x3F80) : (short)0;      // A[i][.] = 1 for output row i = k only
                         const s16x4 ones = {one, one, one, one};
                         s16x4 bh[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) bh[r] = tr4(&dz_b44[r * LDZ]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) accBH = mfma4_bf(ones, bh[r], accBH);
+                        for (int r = 0; r < 4; ++r) accBH = mm4<F16>(ones, bh[r], accBH);
                     }
                 }
                 STAMP(3 + 2 * j);
@@ -1185,13 +1224,13 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int v = 0; v < 8; ++v) {
                         const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
                         const bf16x8 b = join8(tr4(&a_t32[v * S::SPW]), tr4(&a_t32[v * S::SPW + LDZ]));
-                        accW[j >> 1] = mfma_bf(a, b, accW[j >> 1]);
+                        accW[j >> 1] = mm32<F16>(a, b, accW[j >> 1]);
                     }
                 }
                 if (S::DZB == 1) barrier();                                    // one buffer: everyone is done reading before it is replaced
                 STAMP(4 + 2 * j);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4(dpk[k][t >> 1], t & 1);
+                for (int t = 0; t < 4; ++t) dzc[t] = acc[t] * unpack4<F16>(dpk[k][t >> 1], t & 1);
             }
             // ---------- phase NH, layer 1: dX = W1^T dZ1 for the grid slots (tile t = slots 4t .. 4t+3); tiles 0 .. NG0T-1 (the G0 channels) keep
             // their running sums over the rounds in the product's C operand; the dZ1 fragments are the dZ1 image of dW1
@@ -1205,9 +1244,9 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                 for (int t = NG0T; t < NDX; ++t) dxacc[t] = f32x4(0.f);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 bf = cvt_pair(dzc[2 * s], dzc[2 * s + 1]);
+                    const bf16x8 bf = cvt_pair<F16>(dzc[2 * s], dzc[2 * s + 1]);
                     st_frag(&dz_st[32 * s], bf);
-                    kstep_b<NDX, false, KPF>(dxacc, bf, [&](int t) {
+                    kstep_b<NDX, false, KPF, F16>(dxacc, bf, [&](int t) {
                         const int co = 32 * (t >> 1) + 4 * (t & 1);
                         return join8(tr4(&w1_tr[32 * s * LD1 + co]), tr4(&w1_tr[(32 * s + 16) * LD1 + co]));
                     });
@@ -1264,7 +1303,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                             for (int v = 0; v < 8; ++v) {
                                 const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
                                 const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
-                                accW[S::D1SLOT + i] = mfma_bf(a, b, accW[S::D1SLOT + i]);
+                                accW[S::D1SLOT + i] = mm32<F16>(a, b, accW[S::D1SLOT + i]);
                             }
                         }
                     }
@@ -1278,7 +1317,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         for (int v = 0; v < 8; ++v) {
                             const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
                             const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
-                            accW[NH >> 1] = mfma_bf(a, b, accW[NH >> 1]);
+                            accW[NH >> 1] = mm32<F16>(a, b, accW[NH >> 1]);
                         }
                     }
                 } else if (wave < I::NT1) {
@@ -1291,7 +1330,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                     for (int v = 0; v < 8; ++v) {
                         const bf16x8 a = join8(tr4(&dz_t32[v * S::SPW]), tr4(&dz_t32[v * S::SPW + LDZ]));
                         const bf16x8 b = join8(tr4(&x_t32[v * S::SPW]), tr4(&x_t32[v * S::SPW + LDX]));
-                        c = mfma_bf(a, b, c);
+                        c = mm32<F16>(a, b, c);
                     }
                     if (kh == (NH & 1)) accW[NH >> 1] = c;
                     else accW[S::XSLOT] = c;
@@ -1306,7 +1345,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         for (int uu = 0; uu < 4; ++uu) {
                             const bf16x8 a = join8(tr4(&dz_t16[2 * uu * S::SPW]), tr4(&dz_t16[2 * uu * S::SPW + LDZ]));
                             const bf16x8 b = join8(tr4(&x_t16[2 * uu * S::SPW]), tr4(&x_t16[2 * uu * S::SPW + LDX]));
-                            accT = mfma16_bf(a, b, accT);
+                            accT = mm16<F16>(a, b, accT);
                         }
                     }
                 }
@@ -1318,7 +1357,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
         // ---------- flush of the cell's gradient sums
         if constexpr (TRAIN && ML) {
-            flush_ml<Q, NDX>(p, mo0, mo1, dxacc, g1s, opaque_i(lane));
+            flush_ml<Q, NDX>(p, mo0, mo1, dxacc, g1s, opaque_i(lane), F16 ? p.dz_unscale : 1.0f);
         } else if constexpr (TRAIN) {
             const int ln = opaque_i(lane), g = ln >> 4;
             combine_g1_lanes_q<Q>(g1s, blk_off1, blk, ln, lw, packed, pk, pk_lc);
@@ -1371,7 +1410,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         uint32_t ob = (blk_off0 + (uint32_t)p.g0.at(dx, dy, dz)) * 4u;
                         char* gbase = reinterpret_cast<char*>(p.g0_grad);
 #pragma unroll
-                        for (int c = 0; c < Q::C; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), dxacc[(e * Q::C + c) >> 2][(e * Q::C + c) & 3]);
+                        for (int c = 0; c < Q::C; ++c, ob += pb0) atomicAdd(reinterpret_cast<float*>(gbase + ob), F16 ? dxacc[(e * Q::C + c) >> 2][(e * Q::C + c) & 3] * p.dz_unscale : dxacc[(e * Q::C + c) >> 2][(e * Q::C + c) & 3]);
                     }
                 }
                 uint32_t nz1 = 0u;
@@ -1385,7 +1424,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
                         uint32_t ob = (blk_off1 + (uint32_t)p.g1.at(dx, dy, dz)) * 4u + (uint32_t)(Q::GQ * g) * pb1;
                         char* gbase = reinterpret_cast<char*>(p.g1_grad);
 #pragma unroll
-                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), g1s[c8 * Q::GQ + cc]);
+                        for (int cc = 0; cc < Q::GQ; ++cc, ob += pb1) atomicAdd(reinterpret_cast<float*>(gbase + ob), F16 ? g1s[c8 * Q::GQ + cc] * p.dz_unscale : g1s[c8 * Q::GQ + cc]);
                     }
                 }
             }
@@ -1413,24 +1452,25 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     if (!TRAIN) return;
     // ---------------- one record per workgroup
     float* rec = p.partials + (int64_t)blockIdx.x * S::REC;
+    const float us = F16 ? p.dz_unscale : 1.0f;                      // fp16 products: every sum of dZ products carries the loss scale 2^k; 2^-k is exact
 #pragma unroll
     for (int k = 0; k < S::NACC; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rec[S::REC_W + (wave * S::NACC + k) * 1024 + r * 64 + lane] = accW[k][r];
+        for (int r = 0; r < 16; ++r) rec[S::REC_W + (wave * S::NACC + k) * 1024 + r * 64 + lane] = accW[k][r] * us;
     if constexpr (HALF) {
         if (kh == S::TAIL_HALF) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rec[S::REC_TAIL + wave * 256 + r * 64 + lane] = accT[r];
+            for (int r = 0; r < 4; ++r) rec[S::REC_TAIL + wave * 256 + r * 64 + lane] = accT[r] * us;
         }
     }
     float* tail = rec + S::REC_WAVE + wave * S::WTAIL;
 #pragma unroll
-    for (int k = 0; k < NH; ++k) tail[k * 64 + lane] = accBH[k];
+    for (int k = 0; k < NH; ++k) tail[k * 64 + lane] = accBH[k] * us;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) tail[NH * 64 + 64 * c + lane] = accWOq[c];
+    for (int c = 0; c < 3; ++c) tail[NH * 64 + 64 * c + lane] = accWOq[c] * us;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float v = c < 3 ? accBO[c] : accLoss;
+        float v = c < 3 ? accBO[c] * us : accLoss;
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
         if (lane == 0) tail[NH * 64 + 192 + c] = v;

@@ -5,13 +5,13 @@
 
 namespace nic {
 
-template <class Q, int NL>
+template <class Q, int NL, bool F16 = false>
 static int launch_q16_nl(int mode, const FusedParams& p, int grid, hipStream_t s) {
     const dim3 g(grid), b(512);
-    if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_MSE, NL>), g, b, 0, s, p);
-    else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_IMG, NL>), g, b, 0, s, p);
-    else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_DY, NL>), g, b, 0, s, p);
-    else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_INFER, NL>), g, b, 0, s, p);
+    if (mode == MODE_TRAIN_MSE) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_MSE, NL, F16>), g, b, 0, s, p);
+    else if (mode == MODE_TRAIN_IMG) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_IMG, NL, F16>), g, b, 0, s, p);
+    else if (mode == MODE_TRAIN_DY) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_TRAIN_DY, NL, F16>), g, b, 0, s, p);
+    else if (mode == MODE_INFER) hipLaunchKernelGGL((fused_q16_kernel<Q, MODE_INFER, NL, F16>), g, b, 0, s, p);
     else return NIC_E_UNSUPPORTED;
     return (int)hipGetLastError();
 }
@@ -25,6 +25,7 @@ static int reduce_q16_nl(const float* partials, int n_rec, nic_mlp_grads g, floa
 #define NIC_INSTANTIATE_Q16(METHOD)                                                                                              \
     template <>                                                                                                                  \
     int launch_q16<METHOD>(int n_linear, int mode, const FusedParams& p, int grid, hipStream_t s) {                              \
+        if (p.f16) return n_linear == 5 ? launch_q16_nl<QL<METHOD>, 5, true>(mode, p, grid, s) : launch_q16_nl<QL<METHOD>, 3, true>(mode, p, grid, s); \
         return n_linear == 5 ? launch_q16_nl<QL<METHOD>, 5>(mode, p, grid, s) : launch_q16_nl<QL<METHOD>, 3>(mode, p, grid, s);  \
     }                                                                                                                            \
     template <>                                                                                                                  \

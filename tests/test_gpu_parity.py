@@ -753,6 +753,63 @@ def test_baseline_configs_3_to_5_at_reduced_size(dev):
         assert_rel(one.grad_g0, two.grad_g0, 1e-6, "concurrent fit: grid grads")
 
 
+def test_config5_1080p_fits_at_size(dev):
+    """BASELINE config 5 at its size: 1920 x 1080 fits, each with its own grids [12,481,271] + [12,241,136], decoder and targets.
+    (a) one training step of one fit (the configuration bench.py --workload fits64 runs: split products, aligned origin, in-kernel noise) against the
+    oracle: 32 windows sample for sample, the loss against an independent reduction of the kernel's outputs, and a 1920 x 32 strip as its own launch -
+    every gradient against the oracle's forward + backward; (b) EIGHT such fits launched concurrently on eight streams == their serial results."""
+    from neural_image_compression_v2_amd import _lib, fused
+    HH, WW = 1920, 1080
+    gen = torch.Generator().manual_seed(55)
+    fits = []
+    for k in range(8):
+        fp, _ = O.create_pyramid((HH // 4, WW // 4), 12, 8, dim=2, no_mip=True, generator=gen)
+        if k == 0:
+            assert tuple(fp[0].shape) == (12, 271, 481) and tuple(fp[1].shape) == (12, 136, 241)
+        mlp = O.init_mlp(73, 64, generator=gen)
+        fits.append((fp[0].detach(), fp[1].detach(), mlp, torch.rand(HH * WW, 3, generator=gen)))
+    kw = dict(noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=3, noise_offset=5, split_bf16=True, flags=_lib.NIC_FLAG_ORIGINS_ALIGNED)
+    geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(HH, WW), num_crops=1, **kw)
+    dfits = [(a.to(dev), b.to(dev), [q.to(dev) for q in m.tensors()], t.to(dev)) for a, b, m, t in fits]
+    # ---- (a)
+    g0, g1, mlp, tgt = fits[0]
+    out = fused.fused_forward_backward(geo, dfits[0][0], dfits[0][1], [(0, 0)], dfits[0][2], dfits[0][3], want_y=True)
+    rs = np.random.RandomState(3)
+    for _ in range(32):
+        ox, oy = int(rs.randint(0, HH - 16)), int(rs.randint(0, WW - 16))
+        rows = (torch.arange(ox, ox + 16).repeat_interleave(16) * WW + torch.arange(oy, oy + 16).repeat(16))[::29]
+        noise = torch.stack([O.kernel_noise(1, 73, 8, seed=3, offset=5, sample_base=int(r))[0] for r in rows])
+        x = O.create_decoder_input(g0, g1, [(ox, oy)], (16, 16), 0.25, 0, 6)[::29]
+        assert_rel(out.y[rows.to(dev)], O.mlp_forward(x + noise, mlp), 5e-6, "1080p window rows")
+    loss_ind = ((out.y.double() - dfits[0][3].double()) ** 2).mean()
+    assert abs(float(out.loss) - float(loss_ind)) <= 1e-5 * float(loss_ind)
+    s0, sw, base = 512, 32, 424242
+    t_s = tgt.view(HH, WW, 3)[:, s0:s0 + sw].reshape(-1, 3).contiguous()
+    geo_s = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(HH, sw), num_crops=1, sample_base=base, loss_scale=1.0 / (3.0 * HH * WW), **kw)
+    st = fused.fused_forward_backward(geo_s, dfits[0][0], dfits[0][1], [(0, s0)], dfits[0][2], t_s.to(dev), want_y=True)
+    ref = O.forward_backward(g0, g1, mlp, [(0, s0)], (HH, sw), 0.25, 0, t_s, O.kernel_noise(HH * sw, 73, 8, seed=3, offset=5, sample_base=base), mean_over=HH * WW)
+    assert_rel(st.y, ref.y, 5e-6, "1080p strip: y")
+    assert_rel(st.loss, ref.loss, 1e-5, "1080p strip: loss")
+    for nme, p_, q_ in zip(["G0", "G1", "W1", "b1", "W2", "b2", "W3", "b3"], [st.grad_g0, st.grad_g1] + st.grad_mlp, [ref.grad_g0, ref.grad_g1] + ref.grad_mlp):
+        assert_rel(p_, q_, 1e-4, "1080p strip: " + nme)
+    # ---- (b)
+    alone = [fused.fused_forward_backward(geo, a, b, [(0, 0)], prm, tg) for a, b, prm, tg in dfits]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in dfits]
+    together = []
+    for stream, (a, b, prm, tg) in zip(streams, dfits):
+        with torch.cuda.stream(stream):
+            together.append(fused.fused_forward_backward(geo, a, b, [(0, 0)], prm, tg))
+    torch.cuda.synchronize()
+    for one, two in zip(alone, together):
+        assert_exact(one.loss, two.loss, "concurrent 1080p fit: loss")
+        for a, b in zip(one.grad_mlp, two.grad_mlp):
+            assert_exact(a, b, "concurrent 1080p fit: decoder grads")
+        assert_rel(one.grad_g0, two.grad_g0, 1e-5, "concurrent 1080p fit: grid grads")
+        assert_rel(one.grad_g1, two.grad_g1, 1e-5, "concurrent 1080p fit: grid grads")
+    assert_exact(alone[0].loss, out.loss, "the timed fit == the checked fit")
+
+
 def test_fused_autograd_function(dev):
     """FusedGridMLP: arbitrary downstream loss, gradients through the recompute-backward kernel"""
     from neural_image_compression_v2_amd import fused
@@ -1530,6 +1587,25 @@ def test_full_size_4k_properties(dev, split):
     assert_rel(a2.loss, a.loss, 1e-6, "run to run: loss")
     for p_, q_ in zip(a.grad_mlp, a2.grad_mlp):
         assert_rel(p_, q_, 1e-5, "run to run: decoder grads")
+    # (f) full-size GRADIENT parity: the strip [1280, 1344) of image axis 1 - 2160 x 64 px - as its own launch with the global sample
+    #     numbering (sample_base) and the global mean (loss_scale): the SAME outputs as the whole-image launch, bit for bit, and every gradient - decoder and
+    #     both grids, dense - against the oracle's forward + backward of that strip at the small-case tolerances (image_compression.py:258-265)
+    s0, sw_ = 1280, 64
+    rows = (torch.arange(H)[:, None] * W + torch.arange(s0, s0 + sw_)[None, :]).reshape(-1)
+    tgt_strip = target.view(H, W, 3)[:, s0:s0 + sw_].reshape(-1, 3).contiguous()
+    # the whole-image launch numbers sample (x, y) as x W + y; a strip launch numbers its own samples x sw + (y - s0): restate the noise of the strip's own ids
+    base = 987654321
+    geo_s = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(H, sw_), num_crops=1, sample_base=base, loss_scale=1.0 / (3.0 * N), **kw)
+    st = fused.fused_forward_backward(geo_s, g0d, g1d, [(0, s0)], params, tgt_strip, want_y=True)
+    noise_s = O.kernel_noise(H * sw_, 73, 8, seed=7, offset=3, sample_base=base)
+    ref = O.forward_backward(g0, g1, mlp, [(0, s0)], (H, sw_), 0.25, 0, tgt_strip.cpu(), noise_s, mean_over=N)
+    assert_rel(st.y, ref.y, 5e-6, "strip: y")
+    assert_rel(st.loss, ref.loss, 1e-5, "strip: loss")
+    assert_rel(st.grad_g0, ref.grad_g0, 1e-4, "strip: grad G0")
+    assert_rel(st.grad_g1, ref.grad_g1, 1e-4, "strip: grad G1")
+    for nme, p_, q_ in zip(["W1", "b1", "W2", "b2", "W3", "b3"], st.grad_mlp, ref.grad_mlp):
+        assert_rel(p_, q_, 1e-4, "strip: " + nme)
+    del st, ref, noise_s
     if not split:
         return
     # (e) rank 4 of an 8-GPU stripe-sharded bench step: the stripe [1920, 2400) of image axis 1, 8 passes, global sample ids -
@@ -1604,6 +1680,24 @@ def test_full_size_video_slab_properties(dev, method):
     assert torch.equal(again.loss, out.loss)
     for p_, q_ in zip(again.grad_mlp, out.grad_mlp):
         assert torch.equal(p_, q_), "decoder gradients are bit-stable run to run"
+    # (f) full-size GRADIENT parity: a 64 x 1080 x 4 sub-slab (z in [800, 804)) as its own launch with the global sample numbering
+    #     and the global mean - every gradient against the oracle's forward + backward at the small-case tolerances (image_compression.py:258-265)
+    zq = 4
+    gq = torch.Generator().manual_seed(77)
+    tq = torch.rand(kw["extent"][0] * kw["extent"][1] * zq, 3, generator=gq)
+    base_q = 5 * int(target.shape[0]) + 11
+    kq4 = dict(kw, extent=(kw["extent"][0], kw["extent"][1], zq), sample_base=base_q)
+    st = fused.fused_forward_backward(fused.PathGeometry(split_bf16=True, **kq4), g0d, g1d, [(0, 0, 800)], params, tq.to(dev), want_y=True)
+    cin_q = O.decoder_input_channels(12, 6, 3, method)
+    noise_q = O.kernel_noise(tq.shape[0], cin_q, 8, seed=kw["noise_seed"], offset=kw["noise_offset"], sample_base=base_q)
+    ref = O.forward_backward(g0, g1, mlp, [(0, 0, 800)], kq4["extent"], 0.25, 0, tq, noise_q, method=method, use_tri_pe=method == 3,
+                             mean_over=n_glob)
+    assert_rel(st.y, ref.y, 5e-6, "sub-slab: y")
+    assert_rel(st.loss, ref.loss, 1e-5, "sub-slab: loss")
+    assert_rel(st.grad_g0, ref.grad_g0, 1e-4, "sub-slab: grad G0")
+    assert_rel(st.grad_g1, ref.grad_g1, 1e-4, "sub-slab: grad G1")
+    for nme, p_, q_ in zip(["W1", "b1", "W2", "b2", "W3", "b3"], st.grad_mlp, ref.grad_mlp):
+        assert_rel(p_, q_, 1e-4, "sub-slab: " + nme)
 
 
 def test_kernel_noise_world_size_invariance(dev):
