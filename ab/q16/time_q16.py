@@ -20,7 +20,8 @@ org = torch.zeros(1, 2, dtype=torch.int32, device=dev)
 res = {}
 for name, nl, kw, gdt in [("split_nl3", 3, dict(split_bf16=True), torch.float32), ("bf16_nl3", 3, dict(bf16=True), torch.float32),
                           ("bf16_nl3_g16", 3, dict(bf16=True), torch.bfloat16), ("split_nl5", 5, dict(split_bf16=True), torch.float32),
-                          ("bf16_nl5", 5, dict(bf16=True), torch.float32), ("bf16_nl5_g16", 5, dict(bf16=True), torch.bfloat16)]:
+                          ("bf16_nl5", 5, dict(bf16=True), torch.float32), ("bf16_nl5_g16", 5, dict(bf16=True), torch.bfloat16),
+                          ("fp16_nl3", 3, dict(fp16=True), torch.float32), ("fp16_nl5", 5, dict(fp16=True), torch.float32), ("fp16_nl5_g16", 5, dict(fp16=True), torch.float16)]:
     if which and name not in which:
         continue
     dec = ColorDecoder(73, 64, nl).to(dev)
@@ -47,7 +48,7 @@ for method in (3, 4):
     dec = ColorDecoder(cin, 64, 3).to(dev)
     params = [p.detach() for p in dec.linear_params()]
     for name, kw, gdt in [(f"m{method}_split", dict(split_bf16=True), torch.float32), (f"m{method}_bf16", dict(bf16=True), torch.float32),
-                          (f"m{method}_bf16_g16", dict(bf16=True), torch.bfloat16)]:
+                          (f"m{method}_bf16_g16", dict(bf16=True), torch.bfloat16), (f"m{method}_fp16", dict(fp16=True), torch.float32)]:
         if which and name not in which:
             continue
         a, b = fp3[0].detach().to(gdt), fp3[1].detach().to(gdt)

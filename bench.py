@@ -73,8 +73,8 @@ def work_per_sample(dim, method, n_linear=3, grid_bytes=4, target_bytes=4):
 
 
 def kernel_name(dim, method, precision, n_linear):
-    if precision == "bf16":
-        return f"fused_q16_kernel<QL<{method if dim == 3 else 1}>, MODE_TRAIN, NL = {n_linear}> (8 waves x 16 samples, plain bf16 products)"
+    if precision in ("bf16", "fp16"):
+        return f"fused_q16_kernel<QL<{method if dim == 3 else 1}>, MODE_TRAIN, NL = {n_linear}> (8 waves x 16 samples, plain {precision} products)"
     if dim == 2 and n_linear == 5:
         return "fused_mlpn_kernel<Layout<1>, MODE_TRAIN, 5> (4 waves x 16 samples, split-bf16 products)"
     if dim == 2:
@@ -83,7 +83,7 @@ def kernel_name(dim, method, precision, n_linear):
     return f"fused_kernel<Layout<{method}>, SRC_ENCODE, MODE_TRAIN, float, {'PREC_CHAIN' if precision == 'split' else 'PREC_F32'}>"
 
 
-DTYPE_NAME = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate"}
+DTYPE_NAME = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate", "fp16": "fp16 operands, f32 accumulate"}
 
 
 def synthetic_image():
@@ -278,7 +278,7 @@ class Fit:
         return self.fused.PathGeometry(dim=self.dim, method=self.method, step_number=0.25, mip_level=0, extent=tuple(extent), num_crops=ncrops,
                                        passes=passes, noise_mode=_lib.NIC_NOISE_KERNEL, noise_seed=7, noise_offset=i, sample_base=sample_base,
                                        loss_scale=None if n_global is None else 1.0 / (3.0 * n_global),
-                                       flags=_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0, split_bf16=pr == "split", bf16=pr == "bf16")
+                                       flags=_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0, split_bf16=pr == "split", bf16=pr == "bf16", fp16=pr == "fp16")
 
     def fwd_bwd(self, geo, org, target, events=None):
         g0, g1 = self.grids
@@ -449,7 +449,7 @@ def run_sharded(args, rank, world, dev):
     if args.stat_launches > 0:
         stat_main = kernel_only_leg(fit, args.stat_launches)
         if fit.mirror is None and fit.nl == 3 and vworld == 1:
-            for other in ("split", "f32", "bf16"):
+            for other in ("split", "f32", "bf16", "fp16"):
                 if other != args.precision:
                     extra[other] = kernel_only_leg(fit, max(args.stat_launches // 2, 10), precision=other)
     else:
@@ -614,7 +614,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stat-launches", type=int, default=120, help="launches of the post-run statistics leg (median / p10 / p90 of the kernel time); 0: skip the extra legs")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed kernel launches before the W warm-up steps (clock ramp)")
-    ap.add_argument("--precision", choices=["split", "f32", "bf16"], default="split",
+    ap.add_argument("--precision", choices=["split", "f32", "bf16", "fp16"], default="split",
                     help="split: every matrix product of the step as hi + lo bf16 pairs on the bf16 matrix pipe, fp32 accumulate (gradients "
                          "within 5e-6 of the fp32 kernel; the product's default); f32: v_mfma_f32_32x32x2_f32 throughout; bf16: plain bf16 products")
     ap.add_argument("--decoder", type=int, choices=[3, 5], default=3, help="Linear layers of the decoder: 3 (the reference) or 5 (the north star's \"4 x 64\")")

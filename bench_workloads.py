@@ -71,7 +71,7 @@ def _adam(lib, _lib, st, out, i, total, stream):
     _lib.check(lib.nic_adam_multi(tab, 8, 0.9, 0.999, 1e-8, stream), "nic_adam_multi")
 
 
-_DT = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate"}
+_DT = {"split": "bf16x2-split operands, f32 accumulate", "f32": "f32", "bf16": "bf16 operands, f32 accumulate", "fp16": "fp16 operands, f32 accumulate"}
 
 
 def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=True, shapes=None):
@@ -149,7 +149,7 @@ def _run_default(args, dev):
     from neural_image_compression_v2_amd.var2 import Settings
     graph = int(getattr(args, "graph", 0) or 0)
     n_ep = args.warmup + args.steps + 1 if not graph else int(math.ceil((1 + graph * (1 + (args.warmup + args.steps) // graph)) / 0.95)) + 1
-    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=n_ep, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16",
+    cfg = Settings(IMAGE_SIZE=512, NUM_EPOCHS=n_ep, TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision in ("bf16", "fp16"), TF_PLAIN_FP16=args.precision == "fp16",
                    TF_DEVICE_SAMPLER=bool(graph))
     S = cfg.IMAGE_SIZE
     u = torch.linspace(0, 1, S)
@@ -179,7 +179,7 @@ def _run_default3d(args, dev, method, size):
     graph = int(getattr(args, "graph", 0) or 0)
     cfg = Settings(IMAGE_SIZE=size, IMAGE_3D_SIZE=size, IMAGE_DIMENSION=3, COMPRESSION_METHOD=method, CROP_MIP_LEVEL=5,
                    NUM_EPOCHS=(args.warmup + args.steps + 1 if not graph else int(math.ceil((1 + graph * (1 + (args.warmup + args.steps) // graph)) / 0.95)) + 1),
-                   TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision == "bf16", TF_DEVICE_SAMPLER=bool(graph))
+                   TF_NO_MIP=True, TF_SPLIT_BF16=args.precision != "f32", TF_PLAIN_BF16=args.precision in ("bf16", "fp16"), TF_PLAIN_FP16=args.precision == "fp16", TF_DEVICE_SAMPLER=bool(graph))
     g = torch.Generator(device="cpu").manual_seed(5)
     vol = torch.randint(0, 256, (3, size, size, size), generator=g, dtype=torch.uint8)
     ic = ImageCompression(cfg, dev, seed=0)
@@ -218,7 +218,7 @@ def _run_fits8(args, dev):
     def one(k, i, max_wg):
         st = fits[k]
         geo = fused.PathGeometry(dim=2, method=1, step_number=0.25, mip_level=0, extent=(HH, WW), num_crops=1, noise_mode=_lib.NIC_NOISE_KERNEL,
-                                 noise_seed=7 + k, noise_offset=i, split_bf16=args.precision == "split", bf16=args.precision == "bf16", max_workgroups=max_wg)
+                                 noise_seed=7 + k, noise_offset=i, split_bf16=args.precision == "split", bf16=args.precision == "bf16", fp16=args.precision == "fp16", max_workgroups=max_wg)
         out = fused.fused_forward_backward(geo, st["g0"], st["g1"], org, st["params"], targets[k], flat=st["flat"])
         st["flat"] = out.flat
         _adam(lib, _lib, st, out, i, total, _lib.stream_ptr(dev))

@@ -26,6 +26,7 @@ NIC_FLAG_MLPN = 8
 NIC_FLAG_GRID_BF16 = 16
 NIC_FLAG_GRID_FP16 = 32
 NIC_FLAG_BF16 = 64
+NIC_FLAG_FP16 = 128
 NIC_MAX_LINEAR = 5
 
 
@@ -39,7 +40,7 @@ class NicPathDesc(ctypes.Structure):
         ("g1_nodes", ctypes.c_int32 * 3), ("pe_div", ctypes.c_float * 8), ("noise_mode", ctypes.c_int32),
         ("num_bits", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noise_offset", ctypes.c_uint64),
         ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("flags", ctypes.c_int32),
-        ("passes", ctypes.c_int32), ("max_workgroups", ctypes.c_int32),
+        ("passes", ctypes.c_int32), ("dz_scale_log2", ctypes.c_int32), ("max_workgroups", ctypes.c_int32),
     ]
 
 

@@ -601,12 +601,13 @@ int nic_fused_forward(const nic_path_desc* d, const float* g0, const float* g1, 
     if (rc) return rc;
     if (!g0 || !g1 || !origins || !mlp_ok(mlp) || !y) return NIC_E_NULL;
     if (d->noise_mode == NIC_NOISE_TENSOR && !noise) return NIC_E_NULL;
-    if (d->flags & NIC_FLAG_BF16) {
-        // plain-bf16 products: the forward pass of fused_q16_kernel (every layout and channel count those kernels serve, 16-bit grids included)
+    if (d->flags & (NIC_FLAG_BF16 | NIC_FLAG_FP16)) {
+        // plain 16-bit products: the forward pass of fused_q16_kernel (every layout and channel count those kernels serve, 16-bit grids included)
         if ((d->flags & NIC_FLAG_GRID_BF16) && (d->flags & NIC_FLAG_GRID_FP16)) return NIC_E_ARG;
-        if (!cp_default(d) && mlp_depth(mlp) != 3) return NIC_E_UNSUPPORTED;
+        if (!cp_default(d) && (mlp_depth(mlp) != 3 || (d->flags & NIC_FLAG_FP16))) return NIC_E_UNSUPPORTED;
         FusedParams p = zero_params();
         fill_encode(p, d, info_q16(layout, mlp_depth(mlp), d), g0, g1, origins, noise, true);
+        if (d->flags & NIC_FLAG_FP16) set_f16(p, d, false);
         fill_mlp(p, mlp);
         p.y = y;
         p.grid_kind = grid_kind_of(d);

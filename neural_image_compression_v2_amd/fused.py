@@ -85,6 +85,8 @@ class PathGeometry:
     max_workgroups: int = 0              # > 0: the launch takes at most this many workgroups (concurrent fits on separate streams share the CUs)
     mlpn: bool = False                   # 3-layer decoders on the depth-generic kernel that serves 5-layer ones (NIC_FLAG_MLPN: cross-check)
     bf16: bool = False                   # training steps: PLAIN bf16 products (NIC_FLAG_BF16; every layout, 3 or 5 Linear layers) - the north star's "bf16"
+    fp16: bool = False                   # .. on IEEE half operands instead (NIC_FLAG_FP16: the reference's own 16-bit type, utils.py:301-313); default channel counts
+    dz_scale_log2: int = 0               # fp16: dZ is carried as 2^k dZ; 0 = chosen from loss_scale by the MSE entry points (nic_path_desc.dz_scale_log2)
 
     def __post_init__(self):
         if self.dim == 3 and self.method == 3:
@@ -150,6 +152,9 @@ class PathGeometry:
             d.flags |= _lib.NIC_FLAG_MLPN
         if self.bf16:
             d.flags |= _lib.NIC_FLAG_BF16
+        if self.fp16:
+            d.flags |= _lib.NIC_FLAG_FP16
+        d.dz_scale_log2 = int(self.dz_scale_log2)
         if g0.dtype != g1.dtype:
             raise ValueError("G0 and G1 must share a dtype")
         if g0.dtype == torch.bfloat16:
@@ -760,6 +765,10 @@ class FusedGridMLP(torch.autograd.Function):
         gg0, gg1 = torch.zeros_like(g0c), torch.zeros_like(g1c)
         gm = [torch.empty_like(p) for p in pc]
         d = geo.to_desc(g0c, g1c)
+        if geo.fp16 and geo.dz_scale_log2 == 0:
+            # fp16 products carry 2^k dZ: an upstream mean-squared error hands in dY = 2 (y - t) / (3 N) - k brings that to O(1)
+            # (pass PathGeometry.dz_scale_log2 for any other loss)
+            d.dz_scale_log2 = int(round(math.log2(3.0 * geo.n_samples))) + 1
         lib = _lib.load()
         ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(ctypes.byref(d))))
         pad = PaddedMlp.maybe(geo, pc, True)

@@ -102,6 +102,8 @@ class ImageCompression:
     def _geometry(self, fl, mip_level, sample_number, num_crops, method=None, **kw) -> fused.PathGeometry:
         c = self.cfg
         D = c.FP_DIMENSION
+        if kw.get("bf16") and c.TF_PLAIN_FP16 and (c.FEATURE_PYRAMID_CHANNELS, c.PE_CHANNELS) == (12, 6):
+            kw["fp16"] = True                                      # the plain 16-bit products on IEEE half operands (NIC_FLAG_FP16 takes precedence in the library)
         return fused.PathGeometry(dim=D, method=method or self._method(), step_number=pow(2, mip_level - (fl + 1) * 2), mip_level=mip_level,
                                   extent=(sample_number,) * D, num_crops=num_crops, channels=c.FEATURE_PYRAMID_CHANNELS,
                                   pe_channels=c.PE_CHANNELS, hidden=c.HIDDEN_LAYER_CHANNELS, use_tri_pe=c.TF_USE_TRI_PE,
