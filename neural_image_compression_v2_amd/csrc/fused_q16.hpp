@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
     constexpr bool ML = Q::LEVELS > 1;
     constexpr bool HG0 = (HOIST & 1) != 0, HG1 = (HOIST & 2) != 0;
     // GELU derivatives: kept from the forward pass as packed bf16 (8 registers per hidden layer), pinned where they are written (pin())
-    constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && (NL == 5 || Q::NG0 == 2)) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));
+    constexpr bool PIN = NIC_Q16_PIN == 1 || (NIC_Q16_PIN == 2 && (NL == 5 || Q::NG0 >= 2)) || (NIC_Q16_PIN == 3 && (NL == 5 || D == 3));     // NG0 >= 2: method 3 and the multi-level layouts (22 -> 4 spilled registers at L 5 / C 4)
     __shared__ __attribute__((aligned(16))) __bf16 smemq[TRAIN ? S::TOTAL : S::OFF_IMG];
     lds_bf* const sm = (lds_bf*)smemq;
 

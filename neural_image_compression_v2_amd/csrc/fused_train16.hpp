@@ -25,12 +25,6 @@
 #include "fused_kernel.hpp"
 
 
-#ifndef NIC_T16_NOISE_ORDER
-#define NIC_T16_NOISE_ORDER 0        // generator branch first: more copies, not fewer (ISA): off
-#endif
-#ifndef NIC_T16_NOISE_VEC
-#define NIC_T16_NOISE_VEC 0        // measured: the copy goes, the launch gets 2.8 % slower (2.137 -> 2.198 ms): off
-#endif
 #ifndef NIC_T16_HALF16
 #define NIC_T16_HALF16 1
 #endif
@@ -248,48 +242,8 @@ __host__ __device__ constexpr int xs_of_slot(int s) { return s < 15 ? s : s - 1;
 // exactly generator block g of its sample - fields 0..11 the G0 channels, 12..14 the G1 channels, 15..17 the PE rows, 18 the LOD.
 template <class L>
 __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_global, int64_t n_local, int g, float (&xs)[20]) {
-#if NIC_T16_NOISE_VEC
-    // The noise of the 19 real slots as a vector of its own, added once behind the mode switch: with in-place adds inside the three-way branch the
-    // slot values met in a phi and the generator path began with a copy of all of them (16 v_mov_b64 per round in the ISA).
-    float nv[19];
-    if (ns.mode == NIC_NOISE_TENSOR) {
-        const float* row = ns.tensor + n_local * L::CIN;
-#pragma unroll
-        for (int s = 0; s < 20; ++s) {
-            if (s == 15) continue;
-            const int ch0 = slot16_channel(s, 0);
-            if (s == 19) { nv[18] = g == 0 ? row[72] : 0.f; continue; }
-            const int stride = slot16_channel(s, 1) - ch0;        // the channel is affine in g for every other real slot
-            nv[xs_of_slot(s)] = row[ch0 + stride * g];
-        }
-    } else if (ns.mode == NIC_NOISE_KERNEL) {
-        const U4 b = noise_block(ns, sample_global, g);
-#pragma unroll
-        for (int f = 0; f < 18; ++f) nv[f] = noise_field(ns, b, f);
-        const float nl = noise_field(ns, b, 18);
-        nv[18] = g == 0 ? nl : 0.f;
-    } else {
-#pragma unroll
-        for (int f = 0; f < 19; ++f) nv[f] = 0.f;
-    }
-#pragma unroll
-    for (int f = 0; f < 19; ++f) xs[f] += nv[f];
-#else
-#if NIC_T16_NOISE_ORDER
-    if (ns.mode == NIC_NOISE_KERNEL) {
-        const U4 b = noise_block(ns, sample_global, g);
-#pragma unroll
-        for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
-        const float nl = noise_field(ns, b, 18);
-        xs[18] += g == 0 ? nl : 0.f;
-        return;
-    }
-    if (ns.mode != NIC_NOISE_TENSOR) return;
-    {
-#else
     if (ns.mode == NIC_NOISE_NONE) return;
     if (ns.mode == NIC_NOISE_TENSOR) {
-#endif
         const float* row = ns.tensor + n_local * L::CIN;
 #pragma unroll
         for (int s = 0; s < 20; ++s) {
@@ -301,14 +255,11 @@ __device__ __forceinline__ void add_noise16(const NoiseSrc& ns, uint64_t sample_
         }
         return;
     }
-#if !NIC_T16_NOISE_ORDER
     const U4 b = noise_block(ns, sample_global, g);
 #pragma unroll
     for (int f = 0; f < 18; ++f) xs[f] += noise_field(ns, b, f);
     const float nl = noise_field(ns, b, 18);
     xs[18] += g == 0 ? nl : 0.f;
-#endif
-#endif
 }
 
 // G1 sums of the lanes whose G0 cells share a G1 cell are added across lanes before the flush (see combine_g1_lanes)
@@ -383,37 +334,6 @@ __device__ __forceinline__ void preadd_y16(f32x4 (&dxacc)[4], uint32_t off0, uin
     barrier();
 }
 
-// Barrier among the four waves of one HALF of the workgroup (waves 4 kh .. 4 kh + 3).  The two halves never read each other's images
-// (a wave contracts its weight-gradient tiles over the samples of its own half), so the only thing a workgroup-wide s_barrier adds is
-// lockstep: all eight waves in the same phase at the same time, both waves of a SIMD wanting the same pipe.  With one monotonic LDS
-// counter per half the halves drift apart (and are started half a round apart), so a SIMD sees the vector-heavy encode / GELU phases
-// of one wave beside the matrix-heavy phases of the other.  Ordering: the LDS unit processes a wave's DS instructions in issue order,
-// so a wave's image stores (and image reads) are done when its ds_add arrives; whoever sees the count has them behind it.
-#ifndef NIC_T16_HALFBAR
-#define NIC_T16_HALFBAR 0
-#endif
-#ifndef NIC_T16_SKEW
-#define NIC_T16_SKEW 100
-#endif
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int lane) {
-#if NIC_T16_HALFBAR
-    target += 4u;
-    asm volatile("" ::: "memory");
-    if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    // bounded: every wave of a half runs the same number of barriers, so the count always arrives; the bound only turns a logic
-    // error into wrong numbers (caught by the parity tests) instead of a hung GPU
-    for (int spin = 0; spin < (1 << 16); ++spin) {
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((int)(v - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-#elif NIC_T16_HALFBAR == 0
-    wg_lds_barrier();
-#endif      // NIC_T16_HALFBAR < 0: no barrier at all (timing ablation only: the results are wrong)
-}
-
 // =====================================================================================================
 #ifndef NIC_T16_PREADD
 #define NIC_T16_PREADD 2          // 0: every lane flushes its own sums; 1: pre-add along x inside a wave; 2: and along y across the waves of a workgroup
@@ -421,16 +341,8 @@ __device__ __forceinline__ void half_barrier(lds_u32* cnt, uint32_t& target, int
 #ifndef NIC_T16_LB
 #define NIC_T16_LB 512
 #endif
-#ifndef NIC_T16_SB
-#define NIC_T16_SB ((void)0)      // a scheduling barrier between the phases of a round costs 4 %: the compiler overlaps their edges
-#endif
-// NIC_T16_ALTPRIO: the two waves of a SIMD take turns at priority 1, phase by phase (the arbiter otherwise always prefers the older
-// wave, which then idles at the next barrier while the younger one runs alone)
-#ifdef NIC_T16_ALTPRIO
-#define T16_PRIO(ph) do { if (((ph) + kh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
-#else
-#define T16_PRIO(ph) do { } while (0)
-#endif
+// (measured and dropped, DESIGN 8: a scheduling barrier between the phases of a round +4 %; per-half LDS-counter barriers with skewed halves; static /
+//  alternating / time-sliced wave priorities; the noise as a vector behind the mode switch; the generator branch first)
 constexpr int MODE_TRAIN_RGBX = 4;       // this kernel's own mode: MODE_TRAIN_IMG with an interleaved uint8 RGBX target (nic_target_image.is_u8 == 2)
 template <class L, int MODE>
 __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p) {
@@ -483,9 +395,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
     lds_f* const Bs = (lds_f*)(sm + S::OFF_B);                   // b2 [64] in natural order, b3 [4]
     if (tid < kH) Bs[tid] = p.b[1][tid];
     if (tid >= kH && tid < kH + 4) Bs[tid] = tid - kH < 3 ? p.b[2][tid - kH] : 0.f;
-    lds_u32* const bar_cnt = (lds_u32*)(Bs + kH + 4) + __builtin_amdgcn_readfirstlane(tid >> 8);      // one arrival counter per half
-    if (tid < 2) ((lds_u32*)(Bs + kH + 4))[tid] = 0u;
-    uint32_t bar_target = 0u;
     for (int idx = tid; idx < 8 * S::SPW / 2; idx += 512) ((lds_f*)(sm + S::OFF_IMG))[idx] = 0.f;
     __syncthreads();
     const NoiseSrc nsrc = noise_with_step(p.noise, p.step_dev);
@@ -499,12 +408,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
     const int T4 = wave & 3, kh = wave >> 2;
     const int to = T4 >> 1, tk = T4 & 1;
     lds_bf* const img0 = sm + S::OFF_IMG;
-#ifdef NIC_T16_PRIO
-    if (kh == NIC_T16_PRIO) __builtin_amdgcn_s_setprio(1);       // static priority for one wave of every SIMD pair (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
-#if NIC_T16_HALFBAR
-    if (kh) __builtin_amdgcn_s_sleep(NIC_T16_SKEW);           // the second half starts ~ half a round late (64 cycles per unit)
-#endif
 
 #ifdef NIC_STAMPS
     unsigned long long stamp_sum[NIC_NPH];
@@ -664,8 +567,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     add_noise16<L>(nsrc, (uint64_t)(p.d.sample_base + n), n, g, xs);
                 }
                 STAMP(0);    // coordinates, blend, PE, noise
-                T16_PRIO(1);
-                NIC_T16_SB;
                 lds_bf* const imgw = img0 + wave * S::SPW;
                 // ---------- layer 1: Z1[o][n] = sum_rho W1[o][rho] X[rho][n]   (b1 rides on the constant-one slot)
                 {
@@ -724,7 +625,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #pragma unroll
                         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d1[t]));
                     }
-                    NIC_T16_SB;
                     // ---------- layer 2
                     lds_cf* const b2_row = opaque(Bs + 4 * g);
                     lds_bf* const a1_st = (LOFF & 2) ? opaque(img0 + S::OFF_A1 + lo_rZ) : opaque(imgw + S::OFF_A1 + n16 * LDZ + 8 * g);
@@ -749,7 +649,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d2[t]));
                     }
                 }
-                NIC_T16_SB;
                 // ---------- layer 3 (rows 0..2 of a 16-row tile; quarter 0 holds the sample's 3 outputs); the a2 fragments are also
                 // the a2 image of dW3 (the DZ region is free until dZ2 is stored)
                 float yv[3];
@@ -771,7 +670,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                     for (int c = 0; c < 3; ++c) yv[c] = sigmoid_f(z3[c] + ((lds_cf*)Bs)[kH + c]);
                 }
                 STAMP(1);    // layers 1 - 3 with their image stores and GELUs
-                T16_PRIO(2);
                 const bool own = valid && g == 0;
                 if (p.y != nullptr && own) {
 #pragma unroll
@@ -802,7 +700,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
             }
             wave_lds_fence();
-            NIC_T16_SB;
             // ================= backward =================
             f32x4 dz1[4];
             {
@@ -854,7 +751,6 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
                 STAMP(2);    // dZ3 image, dW3, dA2
                 wave_lds_fence();                                              // the dW3 reads of the DZ region are issued: it may be overwritten
-                NIC_T16_SB;
                 // ---------- dA1 = W2^T dZ2; the split dZ2 fragments are the dZ2 image of the weight-gradient product
                 {
                     lds_cbf* const w2_tr = opaque((lds_cbf*)(sm + S::OFF_W2 + ((LOFF & 4) ? lo_tW : (4 * g + q4) * LD2 + 8 * p4)));
@@ -896,10 +792,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
             }
             STAMP(3);    // dA1 (+ dZ2 image), db2
-            half_barrier(bar_cnt, bar_target, lane);
+            wg_lds_barrier();
             STAMP(4);    // wait at barrier 1
-            T16_PRIO(3);
-            NIC_T16_SB;
             // ---------- dW2 tile (to, tk) += sum over the samples of waves 4 kh .. 4 kh + 3 of dZ2[o][n] a1[k][n]
             {
                 const int ln = opaque_i(lane), q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
@@ -917,10 +811,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
             }
             STAMP(5);    // dW2 MFMAs
-            half_barrier(bar_cnt, bar_target, lane);                       // everyone is done reading dZ2 before dZ1 replaces it
+            wg_lds_barrier();                       // everyone is done reading dZ2 before dZ1 replaces it
             STAMP(6);    // wait at barrier 2
-            T16_PRIO(4);
-            NIC_T16_SB;
             // ---------- dX = W1^T dZ1 for the grid slots (tiles 0..3 = slots 0..15); the split dZ1 fragments are the dZ1 image.
             // Tiles 0..2 (the G0 channels) keep their running sums over the rounds in the product's C operand.
             {
@@ -950,9 +842,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
             }
             STAMP(7);    // dX (+ dZ1 image), grid-gradient accumulation
-            half_barrier(bar_cnt, bar_target, lane);
+            wg_lds_barrier();
             STAMP(8);    // wait at barrier 3
-            NIC_T16_SB;
             {
                 const int ln = opaque_i(lane), g = ln >> 4, q4 = (ln & 15) >> 2, p4 = ln & 3, h32 = ln >> 5, cg = (ln >> 4) & 1;
                 lds_cbf* const dz_t32 = opaque((lds_cbf*)(img0 + 32 * to + ((LOFF & 16) ? lo_tZ : (4 * kh) * S::SPW + (4 * q4 + 2 * h32) * LDZ + 16 * cg + 4 * p4)));
@@ -982,9 +873,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                 }
             }
             STAMP(9);    // dW1 MFMAs
-            half_barrier(bar_cnt, bar_target, lane);   // all reads of dZ1 / X done before the next round overwrites them
+            wg_lds_barrier();   // all reads of dZ1 / X done before the next round overwrites them
             STAMP(10);   // wait at barrier 4
-            T16_PRIO(0);
         }  // rounds of one macro-tile
 
         // ---------- flush of the cell's gradient sums
@@ -1007,7 +897,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 #pragma unroll
                     for (int i = 0; i < 12; ++i) mine[(12 + i) * 64] = gacc.g1[i];
                 }
-                half_barrier(bar_cnt, bar_target, lane);
+                wg_lds_barrier();
                 if (leader == wave && tile_ok) {
                     for (int w = wave + 1; w < 4 * kh + 4; ++w) {
                         if (base + w >= t_end || seg_tile0 + ((base + w) >> rg) != tile) break;
@@ -1018,16 +908,13 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
                         for (int i = 0; i < 12; ++i) gacc.g1[i] += theirs[(12 + i) * 64];
                     }
                 }
-                half_barrier(bar_cnt, bar_target, lane);
+                wg_lds_barrier();
                 flush = leader == wave;
             }
-#ifdef NIC_T16_NOFLUSH
-            flush = false;                                                  // timing ablation only
-#endif
             if (flush && NIC_T16_PREADD) preadd_x16(dxacc, blk_off0, ln);
             if (NIC_T16_PREADD >= 2 && rg == 0 && (p.preadd_y || !NIC_PREADD_Y_SMALL)) {      // segment-uniform
                 static_assert(13 * 64 <= S::SPW / 2, "pre-add scratch");
-                preadd_y16<8>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, S::SPW / 2, [&]() { half_barrier(bar_cnt, bar_target, lane); });
+                preadd_y16<8>(dxacc, blk_off0, (uint32_t)p.g0.nx, ln, wave, (lds_f*)img0, S::SPW / 2, [&]() { wg_lds_barrier(); });
             }
             if (flush) {
                 // one predicate per lane and grid instead of one per value: a lane whose 12 sums are all exact zeros (cell outside the
