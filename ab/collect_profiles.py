@@ -46,7 +46,8 @@ json.dump(traffic, open(os.path.join(dst, "traffic.json" if update_traffic else 
 simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
 issue = {"valu_busy": round(4.0 * vals["SQ_ACTIVE_INST_VALU"] / simd_cycles, 4), "mfma_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
          "wait": round(vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], 4), "lds_conflict": round(vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"], 4),
-         "insts_valu_per_mfma": round(vals["SQ_INSTS_VALU"] / max(vals["SQ_INSTS_MFMA"], 1.0), 2), "waves": int(vals["SQ_WAVES"]), "pmc": f"profiles/{tag}_pmc.csv"}
+         "insts_valu_per_mfma": round(vals["SQ_INSTS_VALU"] / max(vals["SQ_INSTS_MFMA"], 1.0), 2), "waves": int(vals["SQ_WAVES"]), "pmc": f"profiles/{tag}_pmc.csv",
+         "hbm_bytes_per_launch": traffic["fused_kernel_bytes_per_launch"]}
 ip = os.path.join(dst, "issue.json")
 allrec = json.load(open(ip)) if os.path.exists(ip) else {}
 kname = [l for l in open(stats).read().split("\n") if kern in l]

@@ -219,12 +219,15 @@ def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic
     common = {"traffic": traffic, "kernel_ms": round(kern_ms, 4), "flop_per_sample": fl, "bytes_per_sample": byt,
               "samples_per_launch": n_launch, "kernel": kernel_name(dim, method, precision, n_linear)}
     if traffic is not None:
-        common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of this tree's split kernel, profiles/r03_z_pmc.csv; not measured in this run)"
+        common["traffic_source"] = TRAFFIC_SOURCE + " (rocprofv3 --pmc passes of this tree's split kernel, profiles/r04_z_pmc.csv; not measured in this run)"
     if stats is not None:
         common["stats"] = stats
     iss = issue_record(common["kernel"])
     if iss is not None:
         common["issue"] = iss
+        if traffic is None and iss.get("hbm_bytes_per_launch") is not None:      # this kernel's own --pmc passes (same launch shape: the 4K workload)
+            common["traffic"] = int(iss["hbm_bytes_per_launch"])
+            common["traffic_source"] = ISSUE_SOURCE + f" ({iss.get('pmc')}; not measured in this run)"
     if grid_nodes is not None:
         cb = cell_granular_bytes(dim, method, n_launch, grid_nodes, grid_bytes)
         cg = cb / (kern_ms * 1e-3) / 1e9
