@@ -11,5 +11,5 @@ for m in 1 2 3 4; do
 done
 wait
 B=$C/build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib$NAME.so $B/simple_kernels.o $B/decoder_general.o $B/fused_capi.o $B/fused_m1.o $B/fused_m2.o $B/fused_m3.o $B/fused_m4.o $B/fused_t16.o $B/fused_mlpn.o $B/fused_qc_*.o $T/fused_q1.o $T/fused_q2.o $T/fused_q3.o $T/fused_q4.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib$NAME.so $B/simple_kernels.o $B/decoder_general.o $B/fused_capi.o $B/fused_m1.o $B/fused_m2.o $B/fused_m3.o $B/fused_m4.o $B/fused_t16.o $B/fused_mlpn.o $B/fused_qc_*.o $B/fused_ml_*.o $T/fused_q1.o $T/fused_q2.o $T/fused_q3.o $T/fused_q4.o
 echo built ab/lib$NAME.so

@@ -36,6 +36,7 @@ Prints ONE JSON line on rank 0 (see the driver contract).  `value` comes from th
 v_mfma_f32_32x32x2_f32; bf16: plain bf16 products (NIC_FLAG_BF16; checked against the precision-emulating oracle, tests/test_gpu_bf16.py).
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -246,6 +247,43 @@ def roofline_record(dim, method, precision, n_linear, kern_ms, n_launch, traffic
                           "unit": "TFLOP/s", "frac_executed": round(mult * flops / PEAK_BF16_TFLOPS, 4)}}
 
 
+class KernelEvents:
+    """(start, end) pair of raw HIP events around the FUSED KERNEL ALONE inside a whole training step: `start` is recorded on the launch stream
+    right before the entry point, `end` by the library right after its fused kernel - before the reduction / optimiser-tail launch
+    (nic_mark_kernel_end).  Drop-in for the (torch.cuda.Event, torch.cuda.Event) pairs ``fused_forward_backward(events=)`` records."""
+    _hip = None
+
+    def __init__(self, lib):
+        if KernelEvents._hip is None:
+            KernelEvents._hip = ctypes.CDLL("libamdhip64.so")             # the runtime torch has already loaded
+        hip = KernelEvents._hip
+        self.lib = lib
+        self.e = [ctypes.c_void_p(), ctypes.c_void_p()]
+        for e in self.e:
+            if hip.hipEventCreate(ctypes.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+
+    class _Rec:
+        def __init__(self, owner, first):
+            self.owner, self.first = owner, first
+
+        def record(self, stream):
+            if self.first:
+                o = self.owner
+                if KernelEvents._hip.hipEventRecord(o.e[0], ctypes.c_void_p(stream.cuda_stream)) != 0:
+                    raise RuntimeError("hipEventRecord failed")
+                o.lib.nic_mark_kernel_end(o.e[1])
+
+    def __getitem__(self, i):
+        return KernelEvents._Rec(self, i == 0)
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        if KernelEvents._hip.hipEventElapsedTime(ctypes.byref(ms), self.e[0], self.e[1]) != 0:
+            raise RuntimeError("hipEventElapsedTime failed (an event was never recorded)")
+        return float(ms.value)
+
+
 class Fit:
     """One coordinate-network fit on one GPU: grids (fp32 masters, optional 16-bit mirrors the kernels gather from), decoder, Adam state,
     the reused gradient bucket and the one-launch optimiser table (built once, step counts and learning rates rewritten per step)."""
@@ -269,6 +307,9 @@ class Fit:
         self.params = [p.detach() for p in dec.linear_params()]
         self.flat = None
         self.table = None
+        self._clean = False                                           # True: the grid-gradient part of the bucket is known to be zero
+        self._tail_done = False
+        self._tail_obj = None
         self.plan = None                                              # StripePlan: Adam over this rank's node rows only
 
     @property
@@ -283,20 +324,54 @@ class Fit:
                                        loss_scale=None if n_global is None else 1.0 / (3.0 * n_global),
                                        flags=_lib.NIC_FLAG_ORIGINS_ALIGNED if aligned else 0, split_bf16=pr == "split", bf16=pr == "bf16", fp16=pr == "fp16")
 
-    def fwd_bwd(self, geo, org, target, events=None):
+    def fwd_bwd(self, geo, org, target, events=None, adam=None):
+        """``adam`` = (i, total_steps): the optimiser step of this training step rides on the reduction launch (nic_path_desc.tail) - two launches
+        per step; the caller's ``adam(out, i, total_steps)`` that follows then launches nothing.  (Stripe-sharded fits exchange gradients between
+        the two: their optimiser stays a launch of its own.)"""
         g0, g1 = self.grids
-        out = self.fused.fused_forward_backward(geo, g0, g1, org, self.params, target, flat=self.flat, events=events)
+        tail = None
+        if adam is not None and self.plan is None and os.environ.get("NIC_NO_TAIL") != "1":
+            tail = lambda gg0, gg1, gm: self._tail(gg0, gg1, gm, *adam)
+        out = self.fused.fused_forward_backward(geo, g0, g1, org, self.params, target, flat=self.flat, events=events, tail=tail, clean=self._clean)
         self.flat = out.flat
+        self._clean = False
+        if self._tail_done:
+            self._clean = True                                        # the tail zeroed the grid gradients it read (NIC_ADAM_ZERO_GRAD)
         return out
 
-    def _build_table(self, out):
-        """nic_adam_tensor entries: the decoder tensors whole; the grids whole, or - stripe-sharded - one block of own node rows per channel"""
+    class _Tail:
+        def __init__(self, fit, arr, n_stream):
+            self.fit, self.arr = fit, arr
+            self.struct = fit._lib.NicStepTail()
+            self.struct.tensors = ctypes.cast(arr, ctypes.c_void_p).value
+            self.struct.count, self.struct.n_stream = len(arr), n_stream
+            self.struct.beta1, self.struct.beta2, self.struct.eps = 0.9, 0.999, 1e-8
+            self.struct_ptr = ctypes.addressof(self.struct)
+
+        def commit(self):
+            self.fit._tail_done = True
+
+    def _tail(self, gg0, gg1, gm, i, total_steps):
+        if self.table is None or self._bucket != gg0.data_ptr():
+            self._build_table(gm, gg0, gg1)
+        if len(self.table) != 1:
+            return None
+        arr, lrs = self.table[0]
+        if self._tail_obj is None or self._tail_obj.arr is not arr:
+            self._tail_obj = Fit._Tail(self, arr, 2)                  # entries 0, 1: the grids (streamed); the rest: the decoder
+        cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))
+        for k, lr in enumerate(lrs):
+            arr[k].step = i + 1
+            arr[k].lr = lr * cos
+        return self._tail_obj
+
+    def _build_table(self, gm, gg0, gg1):
+        """nic_adam_tensor entries: the grids whole (zeroing their gradient buckets as they go), or - stripe-sharded - one block of own node rows
+        per channel; the decoder tensors whole"""
         _lib = self._lib
         q_lo = -(2 ** 8 - 1) / 2 ** 9
         ent = []                                                      # (param, grad, m, v, lr, clamp, mirror)
-        for p, g in zip(self.params, out.grad_mlp):
-            ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.005, (1.0, -1.0), None))
-        for level, (p, g) in enumerate(zip(self.master, (out.grad_g0, out.grad_g1))):
+        for level, (p, g) in enumerate(zip(self.master, (gg0, gg1))):
             mir = None if self.mirror is None else self.mirror[level]
             if self.plan is None:
                 ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.01, (q_lo, 0.5), mir))
@@ -306,6 +381,9 @@ class Fit:
                 tens = (p, g) if mir is None else (p, g, mir)
                 for c, blk in enumerate(stripe_param_blocks(self.plan, level, *tens)):
                     ent.append((blk[0], blk[1], m[c], v[c], 0.01, (q_lo, 0.5), blk[2] if mir is not None else None))
+        n_grid = len(ent)
+        for p, g in zip(self.params, gm):
+            ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.005, (1.0, -1.0), None))
         for e in ent:
             assert e[0].is_contiguous() and e[1].is_contiguous() and (e[6] is None or e[6].is_contiguous())
         tabs = []
@@ -313,16 +391,22 @@ class Fit:
             chunk = ent[i:i + _lib.NIC_ADAM_MAX_TENSORS]
             arr = (_lib.NicAdamTensor * len(chunk))()
             for k, (p, g, m, v, lr, (lo, hi), mir) in enumerate(chunk):
+                # the grid entries zero the gradient rows they read: the bucket is clean for the next step without a fill launch (a rank's samples
+                # only ever touch its own node rows)
                 arr[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, lr, lo, hi,
-                                            0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), 0)
+                                            0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2),
+                                            _lib.NIC_ADAM_ZERO_GRAD if i + k < n_grid else 0)
             tabs.append((arr, [e[4] for e in chunk]))
-        self.table, self._keep, self._bucket = tabs, ent, out.flat.data_ptr()
+        self.table, self._keep, self._bucket = tabs, ent, gg0.data_ptr()
 
     def adam(self, out, i, total_steps):
         """Adam (lr 0.005 decoder / 0.01 grids, image_compression.py:361-364) x CosineAnnealingLR(T_max) + the grids' clamp: one launch
-        (two when the stripe-sharded table exceeds NIC_ADAM_MAX_TENSORS entries)"""
-        if self.table is None or self._bucket != out.flat.data_ptr():
-            self._build_table(out)
+        (two when the stripe-sharded table exceeds NIC_ADAM_MAX_TENSORS entries) - or none, when it rode on the step's reduction (fwd_bwd(adam=))"""
+        if self._tail_done:
+            self._tail_done = False
+            return
+        if self.table is None or self._bucket != out.grad_g0.data_ptr():
+            self._build_table(out.grad_mlp, out.grad_g0, out.grad_g1)
         cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))
         st = self._lib.stream_ptr(self.dev)
         for arr, lrs in self.table:
@@ -330,6 +414,7 @@ class Fit:
                 arr[k].step = i + 1
                 arr[k].lr = lr * cos
             self._lib.check(self.lib.nic_adam_multi(arr, len(lrs), 0.9, 0.999, 1e-8, st), "nic_adam_multi")
+        self._clean = True
 
     def n_params(self):
         return sum(p.numel() for p in self.params) + sum(g.numel() for g in self.master)
@@ -382,11 +467,11 @@ def run_sharded(args, rank, world, dev):
             sl = img[:, :, start:start + extent[-1]]
             target = sl.permute(1, 2, 0).reshape(-1, 3).repeat(passes, 1).contiguous().to(dev)
     total_steps = args.warmup + args.steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [KernelEvents(fit.lib) for _ in range(args.steps)]
     n_small = [None]
 
     def step(i, events=None):
-        out = fit.fwd_bwd(fit.geometry(i, extent, 1, passes, base_mine, n_global), org, target, events)
+        out = fit.fwd_bwd(fit.geometry(i, extent, 1, passes, base_mine, n_global), org, target, events, adam=None if world > 1 else (i, total_steps))
         if stripes:
             if n_small[0] is None:
                 n_small[0] = fused.grad_bucket_layout(fused.PathGeometry(dim, method, 0.25, 0, extent, 1), *fit.grids, n_linear=fit.nl)[0][1 + 2 * fit.nl]
@@ -399,12 +484,12 @@ def run_sharded(args, rank, world, dev):
 
     def kernel_only_leg(f, launches, precision=None, tgt=None):
         """per-launch HIP-event times of the fused kernel alone (no optimiser: the parameters stay put), same inputs and flags"""
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        evs = [KernelEvents(f.lib) for _ in range(launches)]
         for j in range(launches + 3):
             f.fwd_bwd(f.geometry(total_steps + j, extent, 1, passes, base_mine, n_global, precision=precision), org, target if tgt is None else tgt,
                       evs[j - 3] if j >= 3 else None)
         torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in evs]
+        return [e.elapsed_ms() for e in evs]
 
     # untimed: bring the clocks up before the W warm-up steps (a 45 ms timed region right after an idle start has no ramp margin)
     t_pre = time.perf_counter()
@@ -435,7 +520,7 @@ def run_sharded(args, rank, world, dev):
         if fit.mirror is not None:
             for m, p in zip(fit.mirror, fit.master):
                 m.copy_(p)
-    timed_kernel_ms = [a.elapsed_time(b) for a, b in ev]               # fused kernel (+ its ~10 us partial reduction)
+    timed_kernel_ms = [e.elapsed_ms() for e in ev]                     # the fused kernel alone (nic_mark_kernel_end)
     kern_ms = float(np.mean(timed_kernel_ms))
     psnr = None
     if not video:
@@ -464,10 +549,10 @@ def run_sharded(args, rank, world, dev):
     if args.stat_launches > 0 and not video and vworld == 1 and not (args.decoder == 5 and args.precision == "bf16" and gdt == torch.bfloat16):
         f5 = Fit(dev, 2, 1, grid_base=(H // 4, W // 4), n_linear=5, precision="bf16", grid_dtype=torch.bfloat16, seed=1)
         k5, w5 = max(args.stat_launches // 4, 10), 3
-        ev5 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k5)]
+        ev5 = [KernelEvents(f5.lib) for _ in range(k5)]
 
         def step5(i, e=None):
-            o = f5.fwd_bwd(f5.geometry(i, extent, 1, passes, base_mine, n_global), org, target, e)
+            o = f5.fwd_bwd(f5.geometry(i, extent, 1, passes, base_mine, n_global), org, target, e, adam=None if world > 1 else (i, w5 + k5))
             f5.adam(o, i, w5 + k5)
             return o
         for i in range(w5):
@@ -478,7 +563,7 @@ def run_sharded(args, rank, world, dev):
             o5 = step5(w5 + i, ev5[i])
         torch.cuda.synchronize()
         dt5 = (time.perf_counter() - t5) / k5
-        km5 = [a.elapsed_time(b) for a, b in ev5]
+        km5 = [e.elapsed_ms() for e in ev5]
         f5s = Fit(dev, 2, 1, grid_base=(H // 4, W // 4), n_linear=5, precision="split", seed=1)
         ks5 = kernel_only_leg(f5s, max(args.stat_launches // 6, 10))
         lit = (dt5, km5, float(o5.loss), ks5, k5, w5)
@@ -572,7 +657,7 @@ def run_fits64(args, rank, world, dev):
     def sweep(i):
         outs = []
         for f, t in zip(fits, targets):
-            o = f.fwd_bwd(f.geometry(i, (HH, WW)), org, t)
+            o = f.fwd_bwd(f.geometry(i, (HH, WW)), org, t, adam=(i, total))
             f.adam(o, i, total)
             outs.append(o)
         return outs

@@ -88,20 +88,20 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
 
     def step(i, ev=None):
         geo = fit.geometry(i, extent, aligned=all(o % 8 == 0 for o in origin))
-        out = fit.fwd_bwd(geo, org, target, ev)
+        out = fit.fwd_bwd(geo, org, target, ev, adam=(i, total))
         fit.adam(out, i, total)
         return out
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [bench.KernelEvents(fit.lib) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i, ev[i])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    kms = [a.elapsed_time(b) for a, b in ev]
+    kms = [e.elapsed_ms() for e in ev]
     gb = 4 if fit.mirror is None else 2
     cin, flop, byt = bench.work_per_sample(dim, method, args.decoder, gb)
     km = float(np.median(kms))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NIC_ABI_VERSION 8
+#define NIC_ABI_VERSION 9
 
 enum {
     NIC_OK = 0,
@@ -60,6 +60,7 @@ enum {
 /* Geometry of one launch: which grid pair, which samples.  Mirrors the arguments of
  * create_g0_g1 / create_g0_g1_3d / create_g0_g1_3d_v2 (fp_def.py:115,148,187) and of
  * create_decoder_input_2d/_3d/_3d_v2 (image_compression.py:71,103,137). */
+struct nic_step_tail;
 typedef struct nic_path_desc {
     int32_t dim;             /* 2 or 3 */
     int32_t method;          /* 1: 2D.  3: 3D, 8 raw G0 corners.  4: 3D, 4 tetrahedral G0 corners (fp_def.py:107-112) */
@@ -94,6 +95,10 @@ typedef struct nic_path_desc {
                               * workgroups (rounded down to a multiple of 8, at least 8): independent fits launched on separate
                               * streams (BASELINE config 5) then share the CUs side by side instead of queueing behind each other's
                               * persistent grids. */
+    const struct nic_step_tail *tail; /* training entry points (nic_fused_forward_backward, _img, _img_dev, nic_fused_backward_dy,
+                              * nic_fused_ml_forward_backward): null, or the optimiser step that follows the launch (image_compression.py:266-269) -
+                              * the reduction of the decoder-gradient records then also runs Adam over every listed tensor (below: nic_step_tail);
+                              * every other entry point: must be null */
 } nic_path_desc;
 /* Every crop origin is a multiple of the cell size 1 / step_number (1 when step_number >= 1), e.g. whole-image passes from
  * origin 0: the launch then covers extent / cell blocks per axis instead of the unaligned upper bound extent / cell + 1
@@ -346,6 +351,29 @@ typedef struct nic_adam_tensor {
 #define NIC_ADAM_ZERO_GRAD 1
 #define NIC_ADAM_SCHED_COL1 2 /* nic_adam_multi_dev: this tensor takes its step size from column 1 of the schedule (the decoder group), else column 0 */
 int nic_adam_multi(const nic_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
+
+/* ---- the optimiser step as the TAIL of the fused training step (nic_path_desc.tail): image_compression.py:263-269 (backward, optimizer.step,
+ *      fp_quantize_clamp) in TWO launches instead of three or four.  A training entry point ends with the reduction of the per-workgroup
+ *      decoder-gradient records; with a tail that launch gets more blocks: the first `n_stream` tensors (the grids: their gradients are complete
+ *      when the fused kernel ends) are streamed by the extra blocks exactly as nic_adam_multi would - NIC_ADAM_ZERO_GRAD, clamp and 16-bit
+ *      mirror included - WHILE the reduction walks the records (it is latency-bound, the streaming HBM-bound); the remaining tensors are the
+ *      decoder's: their .grad must be the nic_mlp_grads buffers of the same call, and the thread that finishes element i of such a gradient
+ *      updates parameter i on the spot.  Same arithmetic as nic_adam_multi after the plain entry point, bit for bit.  count <= NIC_ADAM_MAX_TENSORS;
+ *      sched / sched_rows: nic_adam_multi_dev's device schedule, read with the `step_dev` of nic_fused_forward_backward_img_dev (null: the
+ *      per-tensor .step / .lr are used). */
+/* measurement hook (bench.py's roofline leg): the NEXT training entry point called on this thread records `hip_event` (a hipEvent_t) on its
+ * stream right after its fused kernel - before the reduction / tail launch - so that HIP events can bracket the dominant kernel alone inside
+ * a timed region of whole steps.  One-shot; null clears it. */
+int nic_mark_kernel_end(void *hip_event);
+
+typedef struct nic_step_tail {
+    const nic_adam_tensor *tensors;
+    int32_t count;
+    int32_t n_stream;
+    double beta1, beta2, eps;
+    const float *sched;
+    int64_t sched_rows;
+} nic_step_tail;
 
 /* ---- hipGraph-captured training loops (no reference counterpart: the reference's loop is host Python, image_compression.py:215-303).
  *      The reference's own launchers run 320 000 steps of 8 x 32^3 samples: the GPU needs ~0.1 ms per step, the host loop twice that.

@@ -22,7 +22,7 @@ SOURCES += [f"fused_qc_{l}_{c}_{p}.hip" for l, c, p in [(1, 4, 6), (1, 8, 6), (1
 # multi-level layouts (fused_q16.hpp::QML): (levels, C, n_linear), one translation unit each
 ML_LIST = [(2, 4, 3), (3, 4, 3), (5, 4, 3), (2, 4, 5), (3, 4, 5), (2, 12, 3), (3, 12, 3)]
 SOURCES += [f"fused_ml_{l}_{c}_{n}.hip" for l, c, n in ML_LIST]
-HEADERS = ["nic_device.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", "fused_q16.hpp", "fused_q16_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
+HEADERS = ["nic_device.hpp", "nic_adam.hpp", "fused_kernel.hpp", "fused_launch.hpp", "fused_train16.hpp", "fused_t16.hpp", "fused_mlpn.hpp", "fused_q16.hpp", "fused_q16_launch.hpp", os.path.join("..", "..", "include", "nicv2_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results that vector instructions consume may live in the architectural VGPRs instead of bouncing
 # through v_accvgpr_read / write (split training kernel: 656 -> 423 of them, -0.7 %; fp32 2D 18 -> 0 spills; 3D 170 -> 115 / 135 -> 85)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-amdgpu-mfma-vgpr-form",

@@ -15,7 +15,7 @@ import torch  # imported before the library so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIC_LIB_PATH") or os.path.join(_HERE, "libnicv2_hip.so")   # override: A/B timing of kernel variants only
 
-NIC_ABI_VERSION = 8
+NIC_ABI_VERSION = 9
 NIC_PE_TRIANGULAR, NIC_PE_SINUSOIDAL = 0, 1
 NIC_G1_REFERENCE, NIC_G1_TEXTBOOK, NIC_G1_UNWEIGHTED = 0, 1, 2
 NIC_NOISE_NONE, NIC_NOISE_TENSOR, NIC_NOISE_KERNEL = 0, 1, 2
@@ -41,6 +41,7 @@ class NicPathDesc(ctypes.Structure):
         ("num_bits", ctypes.c_int32), ("noise_seed", ctypes.c_uint64), ("noise_offset", ctypes.c_uint64),
         ("sample_base", ctypes.c_int64), ("loss_scale", ctypes.c_float), ("flags", ctypes.c_int32),
         ("passes", ctypes.c_int32), ("dz_scale_log2", ctypes.c_int32), ("max_workgroups", ctypes.c_int32),
+        ("tail", ctypes.c_void_p),               # const nic_step_tail *: the optimiser step riding on the reduce launch (training entry points)
     ]
 
 
@@ -73,6 +74,12 @@ class NicAdamTensor(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("clamp_lo", ctypes.c_float),
                 ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class NicStepTail(ctypes.Structure):
+    """struct nic_step_tail (include/nicv2_hip.h): the optimiser step as the tail of a fused training step"""
+    _fields_ = [("tensors", ctypes.c_void_p), ("count", ctypes.c_int32), ("n_stream", ctypes.c_int32), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("sched", ctypes.c_void_p), ("sched_rows", ctypes.c_int64)]
 
 
 NIC_STRIPE_MAX_ROWS = 15
@@ -138,6 +145,7 @@ SIGNATURES = {
     "nic_rgbx_resample_axis": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "nic_fused_ml_forward_backward": (_I, [_D, ctypes.POINTER(NicMlPairs), _P, _M, _P, _P, _P, _P, _G, _P, _SZ, _P]),
     "nic_fused_ml_forward": (_I, [_D, ctypes.POINTER(NicMlPairs), _P, _M, _P, _P]),
+    "nic_mark_kernel_end": (_I, [_P]),
     "nic_stripe_pack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
     "nic_stripe_unpack": (_I, [_P, _L, ctypes.POINTER(NicRowSet), _I, _P, _P]),
 }

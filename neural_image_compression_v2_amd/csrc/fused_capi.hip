@@ -88,8 +88,51 @@ int reduce(int layout, const float* partials, int n_waves, nic_mlp_grads g, floa
     }
 }
 
+// ---- the optimiser tail of the call in progress (nic_path_desc.tail -> nic_adam.hpp::StepTail), parked around the reduce dispatch
+thread_local hipEvent_t g_kernel_end = nullptr;               // nic_mark_kernel_end: one-shot
+void mark_kernel_end(hipStream_t s) {
+    if (g_kernel_end) { (void)hipEventRecord(g_kernel_end, s); g_kernel_end = nullptr; }
+}
+thread_local const StepTail* g_tail = nullptr;
+thread_local int64_t g_tail_blocks = 0;
+struct TailScope {
+    StepTail tl;
+    bool on = false;
+    // builds the table of d->tail (null: nothing parked); rc != 0: the tail is malformed
+    int open(const nic_path_desc* d, const nic_mlp_grads* grads, const int64_t* step_dev) {
+        const nic_step_tail* t = d->tail;
+        if (!t) return NIC_OK;
+        if (!t->tensors || !grads) return NIC_E_NULL;
+        if (t->count < 1 || t->count > NIC_ADAM_MAX_TENSORS || t->n_stream < 0 || t->n_stream > t->count) return NIC_E_ARG;
+        if ((t->sched != nullptr) != (step_dev != nullptr) || (t->sched && t->sched_rows < 1)) return NIC_E_ARG;
+        // a decoder entry's gradient is one of the buffers the reduction writes, whole
+        for (int i = t->n_stream; i < t->count; ++i) {
+            bool found = false;
+            for (int k = 0; k < NIC_MAX_LINEAR; ++k) found = found || (t->tensors[i].grad != nullptr && (t->tensors[i].grad == grads->w[k] || t->tensors[i].grad == grads->b[k]));
+            if (!found) return NIC_E_ARG;
+        }
+        int64_t blocks = 0;
+        const int rc = adam_build_table(t->tensors, t->count, t->n_stream, t->beta1, t->beta2, t->eps, t->sched, t->sched_rows, step_dev, tl.t, tl.n_stream, blocks);
+        if (rc) return rc;
+        g_tail = &tl; g_tail_blocks = blocks; on = true;
+        return NIC_OK;
+    }
+    ~TailScope() { if (on) { g_tail = nullptr; g_tail_blocks = 0; } }
+};
+}  // namespace
+namespace nic {
+TailLaunch tail_for(int reduce_blocks) {
+    TailLaunch r;
+    if (g_tail) { r.tl = *g_tail; r.tl.reduce_blocks = reduce_blocks; r.blocks = (unsigned)(reduce_blocks + g_tail_blocks); }
+    else { r.tl.t.count = 0; r.tl.t.sched = nullptr; r.tl.n_stream = 0; r.tl.reduce_blocks = 0x7fffffff; r.blocks = (unsigned)reduce_blocks; }
+    return r;
+}
+}  // namespace nic
+namespace {
+
 int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->num_crops < 1) return NIC_E_SHAPE;
+    if (!training && d->tail) return NIC_E_ARG;                                  // the optimiser tail: training entry points only
     if (d->max_workgroups < 0) return NIC_E_ARG;
     if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
     for (int a = 0; a < d->dim; ++a)
@@ -465,23 +508,30 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (workspace_bytes < (size_t)n_rec * fi.rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = img ? MODE_TRAIN_IMG : (target ? MODE_TRAIN_MSE : MODE_TRAIN_DY);
+    TailScope tail;                                           // nic_path_desc.tail: Adam rides on the reduce launch below
+    rc = tail.open(d, grads, step_dev);
+    if (rc) return rc;
     if (q16) {
         rc = launch_q16_any(layout, p.n_linear, mode, p, grid, s);
         if (rc) return rc;
+        mark_kernel_end(s);
         return reduce_q16_any(layout, p.n_linear, d, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
     }
     if (mlpn) {
         rc = launch_mlpn(layout, p.n_linear, mode, p, grid, s);
         if (rc) return rc;
+        mark_kernel_end(s);
         return launch_reducen(layout, p.n_linear, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
     }
     if (t16) {
         rc = launch_train16(layout, mode, p, grid, s);
         if (rc) return rc;
+        mark_kernel_end(s);
         return launch_reduce16(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
     }
     rc = launch(layout, SRC_ENCODE, mode, p, grid, s);
     if (rc) return rc;
+    mark_kernel_end(s);
     return reduce(layout, p.partials, n_rec, *grads, (target || img) ? loss : nullptr, d->loss_scale, s);
 }
 
@@ -536,6 +586,11 @@ int fill_ml(FusedParams& p, const nic_path_desc* d, const nic_ml_pairs* pr, cons
 
 extern "C" {
 
+int nic_mark_kernel_end(void* hip_event) {
+    g_kernel_end = (hipEvent_t)hip_event;
+    return NIC_OK;
+}
+
 int nic_fused_ml_forward_backward(const nic_path_desc* d, const nic_ml_pairs* pairs, const int32_t* origins, const nic_mlp* mlp, const float* noise,
                                   const float* target, float* y, float* loss, const nic_mlp_grads* grads, void* workspace, size_t workspace_bytes,
                                   void* stream) {
@@ -551,8 +606,12 @@ int nic_fused_ml_forward_backward(const nic_path_desc* d, const nic_ml_pairs* pa
     const int grid = grid_for(p.n_tiles, 1, 8, d->max_workgroups);
     if (workspace_bytes < (size_t)grid * rec * sizeof(float)) return NIC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    TailScope tail;
+    rc = tail.open(d, grads, nullptr);
+    if (rc) return rc;
     rc = launch_ml_any(pairs->levels, d->channels, p.n_linear, d->pe_mode, MODE_TRAIN_MSE, p, grid, s);
     if (rc) return rc;
+    mark_kernel_end(s);
     return reduce_ml_any(pairs->levels, d->channels, p.n_linear, d->pe_mode, p.partials, grid, *grads, loss, d->loss_scale, s);
 }
 

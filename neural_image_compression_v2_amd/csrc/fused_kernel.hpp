@@ -30,6 +30,7 @@
 //     reduce_partials_kernel (bit-stable decoder gradients and loss for a given grid size).
 #pragma once
 #include "nic_device.hpp"
+#include "nic_adam.hpp"
 #ifndef NIC_GROUP_SUM
 #define NIC_GROUP_SUM 1
 #endif
@@ -2081,7 +2082,8 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
 // =====================================================================================================
 // Fixed-order reduction of the per-wave records into the decoder gradients (nn.Linear layouts) and loss.
 template <class L>
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves /* records */, nic_mlp_grads g, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partials, int n_waves /* records */, nic_mlp_grads g, float* loss, float loss_scale, const StepTail tl) {
+    if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = Lds<L>;
     constexpr int KT = S::KT;
     // a block = 32 outputs x 8 slices of the record list (a serial walk over all records per output left the launch
@@ -2137,17 +2139,17 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
             const int to = a / KT, tk = a % KT;
             const int o = 32 * to + row, rho = 32 * tk + col;
             const int ch = rho < S::KPAD ? channel_of_rho<L>(rho) : kSlotZero;
-            if (ch >= 0) { if (g.w[0]) g.w[0][o * L::CIN + ch] = acc; }
-            else if (ch == kSlotOne) { if (g.b[0]) g.b[0][o] = acc; }
+            if (ch >= 0) { if (g.w[0]) tail_store(tl, &g.w[0][o * L::CIN + ch], acc); }
+            else if (ch == kSlotOne) { if (g.b[0]) tail_store(tl, &g.b[0][o], acc); }
         } else {                                                // dW2 tile (to, tk)
             const int q = a - 2 * KT;
-            if (g.w[1]) g.w[1][(32 * (q >> 1) + row) * kH + 32 * (q & 1) + col] = acc;
+            if (g.w[1]) tail_store(tl, &g.w[1][(32 * (q >> 1) + row) * kH + 32 * (q & 1) + col], acc);
         }
     } else {
         const int t = gid - S::NACC * 1024;
-        if (t < 64) { if (g.b[1]) g.b[1][t] = acc; }
-        else if (t < 256) { if (g.w[2]) g.w[2][t - 64] = acc; }            // [3][64] row-major
-        else if (t < 259) { if (g.b[2]) g.b[2][t - 256] = acc; }
+        if (t < 64) { if (g.b[1]) tail_store(tl, &g.b[1][t], acc); }
+        else if (t < 256) { if (g.w[2]) tail_store(tl, &g.w[2][t - 64], acc); }            // [3][64] row-major
+        else if (t < 259) { if (g.b[2]) tail_store(tl, &g.b[2][t - 256], acc); }
         else if (loss) *loss = acc * loss_scale;
     }
 }

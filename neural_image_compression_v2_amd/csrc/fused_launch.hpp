@@ -61,7 +61,8 @@ int launch_reduce(const float* partials, int n_waves, nic_mlp_grads g, float* lo
     int launch_reduce<METHOD>(const float* partials, int n_waves, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) { \
         using L = Layout<METHOD>;                                                                                        \
         const int n = Lds<L>::NACC * 1024 + Lds<L>::TAIL;                                                                          \
-        hipLaunchKernelGGL((reduce_partials_kernel<L>), dim3((n + 31) / 32), dim3(256), 0, s, partials, n_waves, g, loss, loss_scale); \
+        const TailLaunch t = tail_for((n + 31) / 32);                                                                   \
+        hipLaunchKernelGGL((reduce_partials_kernel<L>), dim3(t.blocks), dim3(256), 0, s, partials, n_waves, g, loss, loss_scale, t.tl); \
         return (int)hipGetLastError();                                                                                   \
     }
 

@@ -25,9 +25,10 @@ int launch_mlpn(int layout, int n_linear, int mode, const FusedParams& p, int gr
 template <int NL>
 static int reduce_n(int layout, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
     constexpr int n_out = kH * 73 + kH + (NL - 2) * (kH * kH + kH) + 3 * kH + 3 + 1;
-    const dim3 grid((n_out + 31) / 32), block(256);
-    if (layout == 1) hipLaunchKernelGGL((reducen_kernel<Layout<1>, NL>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale);
-    else hipLaunchKernelGGL((reducen_kernel<Layout<2>, NL>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale);
+    const TailLaunch t = tail_for((n_out + 31) / 32);
+    const dim3 grid(t.blocks), block(256);
+    if (layout == 1) hipLaunchKernelGGL((reducen_kernel<Layout<1>, NL>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale, t.tl);
+    else hipLaunchKernelGGL((reducen_kernel<Layout<2>, NL>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale, t.tl);
     return (int)hipGetLastError();
 }
 int launch_reducen(int layout, int n_linear, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {

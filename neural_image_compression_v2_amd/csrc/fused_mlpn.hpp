@@ -619,7 +619,8 @@ __global__ void __launch_bounds__(256) fused_mlpn_kernel(FusedParams p) {
 // Fixed-order reduction of the records of fused_mlpn_kernel.  Output index space, layer by layer:
 // W1 [64][73] | b1 [64] | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
 template <class L, int NL>
-__global__ void __launch_bounds__(256) reducen_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(256) reducen_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale, const StepTail tl) {
+    if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = LdsN<NL>;
     constexpr int NH = S::NH;
     constexpr int N_W1 = kH * L::CIN, N_HID = kH * kH + kH;
@@ -697,7 +698,8 @@ __global__ void __launch_bounds__(256) reducen_kernel(const float* partials, int
     float acc = red[0][threadIdx.x];
 #pragma unroll
     for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
-    *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
+    if (gid == N_OUT - 1) *dst = acc * loss_scale;
+    else tail_store(tl, dst, acc);
 }
 
 }  // namespace nic

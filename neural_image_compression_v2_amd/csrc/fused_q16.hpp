@@ -1484,7 +1484,8 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 // Fixed-order reduction of the records of fused_q16_kernel.  Output index space, layer by layer:
 // W1 [64][Cin] | b1 [64] | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
 template <class Q, int NL>
-__global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale, const StepTail tl) {
+    if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = LdsQ<Q, NL>;
     using I = QInfo<Q>;
     constexpr int NH = S::NH, KF = I::KF;
@@ -1569,7 +1570,8 @@ __global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const fl
     float acc = red[0][threadIdx.x];
 #pragma unroll
     for (int sl = 1; sl < NIC_RQ_SLICES; ++sl) acc += red[sl][threadIdx.x];
-    *dst = gid == N_OUT - 1 ? acc * loss_scale : acc;
+    if (gid == N_OUT - 1) *dst = acc * loss_scale;
+    else tail_store(tl, dst, acc);
 }
 
 }  // namespace nic

@@ -987,7 +987,8 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 //   [9216, 9536)   per-wave tails: db2 [64] | dW3 [3][64] | db3 [3] | loss | unused - 8 partial sums 320 apart
 constexpr int kR16_SRC = 4096 + 4096 + 1024 + 320;
 template <class L>
-__global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale) {
+__global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale, const StepTail tl) {
+    if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = Lds16;
     __shared__ float red[8][32];
     const int slice = threadIdx.x >> 5;
@@ -1048,7 +1049,8 @@ __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, in
     float acc = red[0][threadIdx.x];
 #pragma unroll
     for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
-    *dst = is_loss ? acc * loss_scale : acc;
+    if (is_loss) *dst = acc * loss_scale;
+    else tail_store(tl, dst, acc);
 }
 
 }  // namespace nic

@@ -2,7 +2,7 @@
 // (one thread per sample), positional encodings on explicit coordinates, the quantisers and uint8
 // codec, PSNR and the fused Adam + clamp step.  All HBM-bound streaming kernels: coalesced accesses,
 // grid-stride loops capped at 2048 blocks.
-#include "nic_device.hpp"
+#include "nic_adam.hpp"
 #include <math.h>
 
 namespace nic {
@@ -278,8 +278,6 @@ __global__ void __launch_bounds__(256) quantize_kernel(const float* src, float* 
         dst[i] = OP == Q_QUANT ? q : __fmul_rn(q, scale);
     }
 }
-// torch.clamp_ (fp_quantize_clamp, fp_def.py:227-232) propagates NaN; fminf / fmaxf would map a diverged parameter to `lo`
-__device__ __forceinline__ float clamp_keep_nan(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
 __global__ void __launch_bounds__(256) clamp_kernel(float* x, int64_t n, float lo, float hi) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         x[i] = clamp_keep_nan(x[i], lo, hi);
@@ -353,85 +351,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, flo
     }
 }
 
-// Multi-tensor form: one launch for the whole parameter list.  A block owns a contiguous 4096-element chunk of one tensor
-// (found by walking the short prefix table), float4 where the chunk is 16-byte aligned in all four arrays.
-struct AdamEntry {
-    float* p; const float* g; float* m; float* v;
-    int64_t n;
-    float step_size, bc2_sqrt, lo, hi;
-    int first_block;
-    uint16_t* p16;       // optional 16-bit mirror of p (NIC_FLAG_GRID_BF16 / _FP16 storage), rewritten with the rounded new value
-    int p16_kind;
-    int zero_g;          // NIC_ADAM_ZERO_GRAD: the gradient is zeroed once read (an atomically accumulated bucket is clean for the next step)
-};
-__device__ __forceinline__ uint16_t to_store16(float x, int kind) {
-    if (kind == 1) return __builtin_bit_cast(uint16_t, (__bf16)x);               // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
-    return __builtin_bit_cast(uint16_t, (_Float16)x);
-}
-struct AdamTable {
-    AdamEntry e[NIC_ADAM_MAX_TENSORS];
-    int count;
-    float b2, omb1, omb2, eps;
-    // hipGraph-captured loops (nic_adam_multi_dev): row *step_dev of a device table [rows][4] = {step_size of column 0, step_size of column 1,
-    // sqrt(bias_correction2), -} replaces the per-launch scalars of entry k (column sched_col[k])
-    const float* sched;
-    const int64_t* step_dev;
-    int64_t sched_rows;
-    unsigned char sched_col[NIC_ADAM_MAX_TENSORS];
-};
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamTable& t, float step_size, float bc2_sqrt,
-                                         float lo, float hi) {
-    m = m + (g - m) * t.omb1;
-    v = v * t.b2 + t.omb2 * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + t.eps;
-    float x = p - step_size * (m / denom);
-    if (lo <= hi) x = clamp_keep_nan(x, lo, hi);
-    p = x;
-}
-constexpr int kAdamChunk = 4096;
-__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) {
-    int k = 0;
-    while (k + 1 < t.count && (int)blockIdx.x >= t.e[k + 1].first_block) ++k;
-    AdamEntry e = t.e[k];
-    if (t.sched != nullptr) {
-        int64_t row = *t.step_dev;
-        row = row < 0 ? 0 : (row >= t.sched_rows ? t.sched_rows - 1 : row);
-        e.step_size = t.sched[4 * row + t.sched_col[k]];
-        e.bc2_sqrt = t.sched[4 * row + 2];
-    }
-    const int64_t base = (int64_t)((int)blockIdx.x - e.first_block) * kAdamChunk;
-    const int64_t left = e.n - base;
-    const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
-    float* p = e.p + base; const float* g = e.g + base; float* m = e.m + base; float* v = e.v + base;
-    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
-    if (vec) {
-        const int n4 = cnt >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-            const float4 gg = reinterpret_cast<const float4*>(g)[i];
-            adam_one(pp.x, gg.x, mm.x, vv.x, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.y, gg.y, mm.y, vv.y, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.z, gg.z, mm.z, vv.z, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            adam_one(pp.w, gg.w, mm.w, vv.w, t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
-            if (e.zero_g) reinterpret_cast<float4*>(const_cast<float*>(g))[i] = float4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int i = 4 * n4 + threadIdx.x; i < cnt; i += 256) {
-            adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            if (e.zero_g) const_cast<float*>(g)[i] = 0.f;
-        }
-    } else {
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            adam_one(p[i], g[i], m[i], v[i], t, e.step_size, e.bc2_sqrt, e.lo, e.hi);
-            if (e.zero_g) const_cast<float*>(g)[i] = 0.f;
-        }
-    }
-    if (e.p16 != nullptr) {                                       // the block re-reads its own chunk of the master (its own stores: visible to it)
-        __syncthreads();
-        uint16_t* q = e.p16 + base;
-        for (int i = threadIdx.x; i < cnt; i += 256) q[i] = to_store16(p[i], e.p16_kind);
-    }
-}
+// Multi-tensor form (nic_adam.hpp): one launch for the whole parameter list, a block per 4096-element chunk of one tensor
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable t) { adam_block(t, t.count, (int)blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------
 // Device-side sampler and resident RGBX targets
@@ -833,33 +754,11 @@ static int adam_multi_impl(const nic_adam_tensor* tensors, int count, double bet
     if (!tensors) return NIC_E_NULL;
     if (count < 0 || count > NIC_ADAM_MAX_TENSORS) return NIC_E_ARG;
     AdamTable t;
-    t.b2 = (float)beta2; t.omb1 = (float)(1.0 - beta1); t.omb2 = (float)(1.0 - beta2); t.eps = (float)eps;
-    int nt = 0;
+    int n_stream = 0;
     int64_t blocks = 0;
-    for (int i = 0; i < count; ++i) {
-        const nic_adam_tensor& a = tensors[i];
-        if (a.n == 0) continue;
-        if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) return NIC_E_NULL;
-        if (a.n < 0 || (a.step < 1 && !sched)) return NIC_E_ARG;
-        const double bc1 = 1.0 - pow(beta1, (double)a.step);
-        const double bc2 = 1.0 - pow(beta2, (double)a.step);
-        AdamEntry& e = t.e[nt++];
-        e.p = a.param; e.g = a.grad; e.m = a.exp_avg; e.v = a.exp_avg_sq; e.n = a.n;
-        e.step_size = (float)(a.lr / bc1);        // formed in double like torch's Python-float step_size, cast once
-        e.bc2_sqrt = (float)sqrt(bc2);
-        e.lo = a.clamp_lo; e.hi = a.clamp_hi;
-        e.p16 = (uint16_t*)a.param16; e.p16_kind = a.param16_kind;
-        if (a.flags & ~(NIC_ADAM_ZERO_GRAD | NIC_ADAM_SCHED_COL1)) return NIC_E_ARG;
-        e.zero_g = (a.flags & NIC_ADAM_ZERO_GRAD) ? 1 : 0;
-        t.sched_col[nt - 1] = (a.flags & NIC_ADAM_SCHED_COL1) ? 1 : 0;
-        if (e.p16 != nullptr && e.p16_kind != 1 && e.p16_kind != 2) return NIC_E_ARG;
-        e.first_block = (int)blocks;
-        blocks += (a.n + kAdamChunk - 1) / kAdamChunk;
-        if (blocks > 0x7fffffff) return NIC_E_ARG;
-    }
-    if (nt == 0) return NIC_OK;
-    t.count = nt;
-    t.sched = sched; t.step_dev = step_dev; t.sched_rows = sched_rows;
+    const int rc = adam_build_table(tensors, count, count, beta1, beta2, eps, sched, sched_rows, step_dev, t, n_stream, blocks);
+    if (rc) return rc;
+    if (t.count == 0) return NIC_OK;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }

@@ -450,9 +450,11 @@ def grad_bucket_layout(geo: PathGeometry, g0: torch.Tensor, g1: torch.Tensor, n_
 @_on_tensor_device
 def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: torch.Tensor,
                            noise: Optional[torch.Tensor] = None, want_y: bool = False,
-                           flat: Optional[torch.Tensor] = None, events=None) -> StepOutput:
+                           flat: Optional[torch.Tensor] = None, events=None, tail=None, clean: bool = False) -> StepOutput:
     """One training step's forward + MSE + backward in one launch (+ the fixed-order partial reduction):
-    image_compression.py:239-265.  Gradients are returned, not accumulated into .grad.  Grids may be bfloat16 / float16 STORAGE (2D,
+    image_compression.py:239-265.  Gradients are returned, not accumulated into .grad.  ``tail``: callable ``(StepOutput views) -> optim.StepTail``
+    or None: the optimiser step rides on the reduction launch (nic_path_desc.tail; ``optim.FusedAdam.step_tail``).  ``clean``: the caller vouches
+    that the grid-gradient part of the reused ``flat`` is zero (the optimiser zeroed what it read, NIC_ADAM_ZERO_GRAD): no fill launch.  Grids may be bfloat16 / float16 STORAGE (2D,
     split_bf16): gathered values are widened to fp32, the returned grid gradients are fp32 tensors of the grids' shapes (feed them to
     ``optim.FusedAdam`` on fp32 masters with ``set_mirror``)."""
     g0 = _lib.require_cuda_grid(grid_storage(g0).detach(), "G0")
@@ -479,7 +481,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
     else:
         if flat.numel() != total or flat.dtype != torch.float32 or not flat.is_cuda:
             raise ValueError("flat gradient buffer has the wrong size / dtype / device")
-        flat.zero_()
+        if not clean:
+            flat.zero_()
     views = [flat[o:o + s] for o, s in zip(offs, sizes)]
     shapes = [p.shape for p in params]
     gm = [views[1 + i].view(shapes[i]) for i in range(2 * nl)]
@@ -495,6 +498,11 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
         d.hidden = FUSED_HIDDEN
     m = pad.m if pad is not None else _mlp_struct(params)
     gs = pad.gs if pad is not None else _grads_struct(gm)
+    th = None
+    if tail is not None and pad is None:     # (zero-padded decoders reduce into padded copies: their step stays a launch of its own)
+        th = tail(gg0, gg1, gm)
+        if th is not None:
+            d.tail = th.struct_ptr
     if events is not None:                   # (start, end) torch.cuda.Event pair recorded on the launch stream
         events[0].record(torch.cuda.current_stream(dev))
     noise_p = _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None)
@@ -508,6 +516,8 @@ def fused_forward_backward(geo: PathGeometry, g0, g1, coord, params, target: tor
             ctypes.byref(d), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(org), ctypes.byref(m), noise_p, _lib.ptr(target), _lib.ptr(y),
             _lib.ptr(views[0]), _lib.ptr(gg0), _lib.ptr(gg1), ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
             "nic_fused_forward_backward")
+    if th is not None:
+        th.commit()
     if pad is not None:
         pad.unpad(gm)
     if events is not None:
@@ -571,7 +581,9 @@ class StepPlan:
         return (grid_storage(g0).data_ptr() == self.g0.data_ptr() and grid_storage(g1).data_ptr() == self.g1.data_ptr() and target is self.target
                 and len(params) == len(self.params) and all(p.data_ptr() == q.data_ptr() for p, q in zip(params, self.params)))
 
-    def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int) -> StepOutput:
+    def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int, tail=None) -> StepOutput:
+        """``tail``: an ``optim.StepTail`` built on this plan's buffers (``FusedAdam.step_tail([(g0, plan.gg0), (g1, plan.gg1)], zip(params, plan.gm))``):
+        the optimiser step rides on the reduction launch; committed here once the launch is queued"""
         geo, dev = self.geo, self.dev
         with torch.cuda.device(dev):
             if isinstance(coord, torch.Tensor) and coord.is_cuda:
@@ -603,10 +615,17 @@ class StepPlan:
             ws = _lib.workspace(dev, int(self.lib.nic_workspace_bytes(ctypes.byref(d))))
             if self.pad is not None:
                 self.pad.pad()
-            _lib.check(self.lib.nic_fused_forward_backward_img(
-                ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
-                self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
-                "nic_fused_forward_backward_img")
+                tail = None                  # zero-padded decoders reduce into padded copies: their step stays a launch of its own
+            d.tail = tail.struct_ptr if tail is not None else None
+            try:
+                _lib.check(self.lib.nic_fused_forward_backward_img(
+                    ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
+                    self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                    "nic_fused_forward_backward_img")
+            finally:
+                d.tail = None
+            if tail is not None:
+                tail.commit()
             if self.pad is not None:
                 self.pad.unpad(self.gm)
         return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)

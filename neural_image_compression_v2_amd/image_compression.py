@@ -265,13 +265,23 @@ class ImageCompression:
             lin = self.decoder.linear_params()
             if plan is None or not plan.matches(fp[2 * fl], fp[2 * fl + 1], lin, target):
                 plan = plans[(fl, lod)] = fused.StepPlan(geo, fp[2 * fl], fp[2 * fl + 1], lin, target)
-            out = plan.run(coord, geo.noise_mode, noise_seed, epoch)
+            # the optimiser step of :266-269 rides on the reduction launch of the fused step (nic_path_desc.tail): two launches per step
+            tail = self._step_tail(fp, fl, plan.gg0, plan.gg1, plan.gm)
+            out = plan.run(coord, geo.noise_mode, noise_seed, epoch, tail=tail)
             plan_used = plan
         else:
             flats = self.__dict__.setdefault("_flat", {})      # one gradient bucket per level, reused: the optimiser's launch table stays valid
-            out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl))
+            out = fused.fused_forward_backward(geo, fp[2 * fl], fp[2 * fl + 1], coord, self.decoder.linear_params(), target, flat=flats.get(fl),
+                                               tail=lambda gg0, gg1, gm: self._step_tail(fp, fl, gg0, gg1, gm))
             flats[fl] = out.flat
         return out, plan_used
+
+    def _step_tail(self, fp, fl, gg0, gg1, gm):
+        """``FusedAdam.step_tail`` for the level pair ``fl`` and the decoder on the given gradient buffers; None: the step stays a launch of its own
+        (another optimiser class, NIC_NO_TAIL=1 - the A/B switch)"""
+        if not isinstance(self.optimizer, FusedAdam) or os.environ.get("NIC_NO_TAIL") == "1":
+            return None
+        return self.optimizer.step_tail([(fp[2 * fl], gg0), (fp[2 * fl + 1], gg1)], list(zip(self.decoder.linear_params(), gm)))
 
     def _train_step_tail(self, fp, epoch, fl, lod, coord, target, noisy, noise_seed, plan_used, loss=None, layerwise=False):
         """the unfused forms of the step (when ``loss`` is None) and what follows every step: optimiser, scheduler, clamp"""

@@ -30,11 +30,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._zero: set = set()
 
     def load_state_dict(self, state_dict) -> None:
-        self._cache = None                                       # the state tensors are replaced
+        self._cache = self._tail_cache = None                    # the state tensors are replaced
         super().load_state_dict(state_dict)
 
     def add_param_group(self, param_group) -> None:
-        self._cache = None
+        self._cache = self._tail_cache = None
         super().add_param_group(param_group)
 
     def zero_grad_in_step(self, params: Iterable[torch.Tensor]) -> None:
@@ -63,12 +63,62 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("the mirror is a contiguous bfloat16 / float16 tensor of the parameter's shape")
         self._mirror[id(param)] = mirror16
 
+    # ---- the step as the TAIL of the fused training launch (nic_path_desc.tail, csrc/nic_adam.hpp): the reduction of the decoder-gradient records
+    # and this optimiser's update in ONE launch - the grids are streamed while the reduction walks the records, the decoder's parameters are updated
+    # by the threads that finish their gradients.  Same arithmetic as step(), bit for bit.
+    @torch.no_grad()
+    def step_tail(self, stream_pairs, decoder_pairs) -> Optional["StepTail"]:
+        """``stream_pairs``: [(parameter, its gradient buffer)] whose gradients are complete when the fused kernel ends (the grids);
+        ``decoder_pairs``: the decoder's tensors with the buffers the step's reduction writes (``StepPlan.gm`` / ``StepOutput.grad_mlp``).  Returns
+        the handle to pass as ``tail=`` to ``fused.fused_forward_backward`` / ``StepPlan.run`` - which commits it once the launch is queued - or
+        None when this optimiser cannot ride on one launch (more than NIC_ADAM_MAX_TENSORS tensors, groups with different betas / eps): the
+        caller then steps the ordinary way.  After a committed tail the next ``step()`` - the reference's call (image_compression.py:266) -
+        launches nothing."""
+        pairs = list(stream_pairs) + list(decoder_pairs)
+        keys = {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups}
+        if len(keys) != 1 or not pairs or len(pairs) > _lib.NIC_ADAM_MAX_TENSORS:
+            return None
+        ptrs = tuple((p.data_ptr(), g.data_ptr()) for p, g in pairs)
+        c = getattr(self, "_tail_cache", None)
+        if c is None or c.ptrs != ptrs or c.n_stream != len(stream_pairs) or c.clamp != self._clamp or c.mirror != {k: id(v) for k, v in self._mirror.items()}:
+            gidx = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+            entries, zeroed = [], set()
+            for i, (p, g) in enumerate(pairs):
+                if id(p) not in gidx:
+                    raise ValueError("a tail parameter is not registered in this optimiser")
+                _lib.require_cuda_f32(p, "parameter")
+                if not (p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda and g.numel() == p.numel()):
+                    raise RuntimeError("tail parameters and gradient buffers are contiguous fp32 device tensors of one size")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                lo, hi = self._clamp.get(id(p), (1.0, -1.0))
+                mir = self._mirror.get(id(p))
+                zero = id(p) in self._zero and i < len(stream_pairs)
+                if zero:
+                    zeroed.add(g.data_ptr())
+                entries.append(_lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                                  int(st["step"].item()), 0.0, lo, hi, 0 if mir is None else mir.data_ptr(),
+                                                  0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), _lib.NIC_ADAM_ZERO_GRAD if zero else 0))
+            (b1, b2, eps), = keys
+            c = self._tail_cache = StepTail(self, (_lib.NicAdamTensor * len(entries))(*entries), len(stream_pairs), (b1, b2, eps), [p for p, _ in pairs],
+                                            [gidx[id(p)] for p, _ in pairs], frozenset(zeroed), ptrs, dict(self._clamp), {k: id(v) for k, v in self._mirror.items()})
+        for i, (p, gi) in enumerate(zip(c.params, c.gidx)):
+            c.arr[i].step = int(self.state[p]["step"].item()) + 1
+            c.arr[i].lr = float(self.param_groups[gi]["lr"])
+        return c
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if getattr(self, "_tail_done", False):
+            self._tail_done = False                              # this step's update rode on the fused launch (step_tail)
+            return loss
         lib = _lib.load()
         if self._fast_step(lib):
             return loss
@@ -224,6 +274,33 @@ class FusedAdam(torch.optim.Optimizer):
         with torch.cuda.device(c["device"]):
             _lib.check(lib.nic_adam_multi(arr, len(plist), b1, b2, eps, _lib.stream_ptr(c["device"])), "nic_adam_multi")
         return True
+
+
+class StepTail:
+    """``FusedAdam.step_tail``'s handle: the nic_step_tail struct of one training step.  ``struct_ptr`` goes into nic_path_desc.tail; ``commit()``
+    (called by the fused wrappers once the launch is queued) advances the optimiser's step counts and makes its next ``step()`` a no-op."""
+
+    def __init__(self, opt, arr, n_stream, key, params, gidx, zeroed, ptrs, clamp, mirror):
+        self.opt, self.arr, self.n_stream, self.key, self.params, self.gidx, self.zeroed = opt, arr, n_stream, key, params, gidx, zeroed
+        self.ptrs, self.clamp, self.mirror = ptrs, clamp, mirror
+        self.struct = _lib.NicStepTail()
+        self.struct.tensors = ctypes.cast(arr, ctypes.c_void_p).value
+        self.struct.count, self.struct.n_stream = len(arr), n_stream
+        self.struct.beta1, self.struct.beta2, self.struct.eps = key
+        self.steps = [opt.state[p]["step"] for p in params]
+
+    @property
+    def struct_ptr(self) -> int:
+        return ctypes.addressof(self.struct)
+
+    def decoder_grad_ptrs(self):
+        return [self.arr[i].grad for i in range(self.n_stream, len(self.arr))]
+
+    def commit(self) -> None:
+        torch._foreach_add_(self.steps, 1)
+        self.opt._zeroed = self.zeroed
+        self.opt._tail_done = True
+        self.opt._cache = None                                   # step()'s table holds the old step counts
 
 
 class DevAdam:

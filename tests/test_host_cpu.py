@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nicv2_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.nic_abi_version() == _lib.NIC_ABI_VERSION == 8
+    assert lib.nic_abi_version() == _lib.NIC_ABI_VERSION == 9
     assert lib.nic_error_string(-2).decode().startswith("unsupported")
     assert lib.nic_decoder_input_channels(2, 1, 12, 6) == 73          # var2.py:114-118
     assert lib.nic_decoder_input_channels(3, 3, 12, 6) == 127
@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_path_desc_layout_matches_the_c_header():
-    from neural_image_compression_v2_amd._lib import NicAdamTensor, NicMlp, NicMlPairs, NicPathDesc, NicTargetImage
+    from neural_image_compression_v2_amd._lib import NicAdamTensor, NicMlp, NicMlPairs, NicPathDesc, NicStepTail, NicTargetImage
     fields = [f[0] for f in NicPathDesc._fields_]
     afields = [f[0] for f in NicAdamTensor._fields_]
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(){",
@@ -63,12 +63,20 @@ def test_path_desc_layout_matches_the_c_header():
     mfields = [f[0] for f in NicMlPairs._fields_]
     prog += ['printf("%zu\\n", sizeof(nic_ml_pairs));']
     prog += [f'printf("%zu\\n", offsetof(nic_ml_pairs, {f}));' for f in mfields]
+    sfields = [f[0] for f in NicStepTail._fields_]
+    prog += ['printf("%zu\\n", sizeof(nic_step_tail));']
+    prog += [f'printf("%zu\\n", offsetof(nic_step_tail, {f}));' for f in sfields]
     prog += ["return 0;}"]
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
         open(src, "w").write("\n".join(prog))
         subprocess.run(["gcc", "-std=c11", src, "-o", exe], check=True)
         vals = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    ns = len(sfields)
+    assert vals[-1 - ns] == ctypes.sizeof(NicStepTail)
+    for f, off in zip(sfields, vals[-ns:]):
+        assert getattr(NicStepTail, f).offset == off, f
+    vals = vals[:-1 - ns]
     nf = len(fields)
     assert vals[0] == ctypes.sizeof(NicPathDesc)
     for f, off in zip(fields, vals[1:1 + nf]):
