@@ -366,54 +366,88 @@ class Fit:
         return self._tail_obj
 
     def _build_table(self, gm, gg0, gg1):
-        """nic_adam_tensor entries: the grids whole (zeroing their gradient buckets as they go), or - stripe-sharded - one block of own node rows
-        per channel; the decoder tensors whole"""
+        """nic_adam_tensor tables.  One fit on one GPU: [G0, G1 (whole, zeroing their gradient buckets as they go) | the decoder tensors] - one
+        launch, or the tail of the step's reduction.  Stripe-sharded: TWO tables - the rank's INTERIOR node rows of both grids (one entry per grid:
+        `reps` = channels runs of rows, moments allocated for the own rows only), whose gradients are final when the fused kernel ends and which
+        therefore run under the all-reduce (``adam_interior``), and the boundary rows + the decoder, which need its result (``adam``)."""
         _lib = self._lib
         q_lo = -(2 ** 8 - 1) / 2 ** 9
-        ent = []                                                      # (param, grad, m, v, lr, clamp, mirror)
+        keep = []
+
+        def entry(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, clamp, mir, off16=0, zero=False, reps=0, stride=0, sstride=0):
+            return _lib.NicAdamTensor(p_ptr, g_ptr, m_ptr, v_ptr, n, 0, lr, clamp[0], clamp[1], 0 if mir is None else mir.data_ptr() + 2 * off16,
+                                      0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2), _lib.NIC_ADAM_ZERO_GRAD if zero else 0,
+                                      reps, 0, stride, sstride)
+        dec = []
+        for p, g in zip(self.params, gm):
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            keep += [m, v]
+            assert p.is_contiguous() and g.is_contiguous()
+            dec.append((entry(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0.005, (1.0, -1.0), None), 0.005))
+        grids, interior, boundary = [], [], []
         for level, (p, g) in enumerate(zip(self.master, (gg0, gg1))):
             mir = None if self.mirror is None else self.mirror[level]
+            assert p.is_contiguous() and g.is_contiguous() and g.shape == p.shape and (mir is None or (mir.is_contiguous() and mir.shape == p.shape))
             if self.plan is None:
-                ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.01, (q_lo, 0.5), mir))
-            else:
-                from neural_image_compression_v2_amd.distributed import stripe_param_blocks, stripe_state
-                m, v = stripe_state(self.plan, level, p), stripe_state(self.plan, level, p)
-                tens = (p, g) if mir is None else (p, g, mir)
-                for c, blk in enumerate(stripe_param_blocks(self.plan, level, *tens)):
-                    ent.append((blk[0], blk[1], m[c], v[c], 0.01, (q_lo, 0.5), blk[2] if mir is not None else None))
-        n_grid = len(ent)
-        for p, g in zip(self.params, gm):
-            ent.append((p, g, torch.zeros_like(p), torch.zeros_like(p), 0.005, (1.0, -1.0), None))
-        for e in ent:
-            assert e[0].is_contiguous() and e[1].is_contiguous() and (e[6] is None or e[6].is_contiguous())
-        tabs = []
-        for i in range(0, len(ent), _lib.NIC_ADAM_MAX_TENSORS):
-            chunk = ent[i:i + _lib.NIC_ADAM_MAX_TENSORS]
-            arr = (_lib.NicAdamTensor * len(chunk))()
-            for k, (p, g, m, v, lr, (lo, hi), mir) in enumerate(chunk):
-                # the grid entries zero the gradient rows they read: the bucket is clean for the next step without a fill launch (a rank's samples
-                # only ever touch its own node rows)
-                arr[k] = _lib.NicAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, lr, lo, hi,
-                                            0 if mir is None else mir.data_ptr(), 0 if mir is None else (1 if mir.dtype == torch.bfloat16 else 2),
-                                            _lib.NIC_ADAM_ZERO_GRAD if i + k < n_grid else 0)
-            tabs.append((arr, [e[4] for e in chunk]))
-        self.table, self._keep, self._bucket = tabs, ent, gg0.data_ptr()
+                m, v = torch.zeros_like(p), torch.zeros_like(p)
+                keep += [m, v]
+                grids.append((entry(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0.01, (q_lo, 0.5), mir, zero=True), 0.01))
+                continue
+            from neural_image_compression_v2_amd.distributed import stripe_row_parts, stripe_state
+            m, v = stripe_state(self.plan, level, p), stripe_state(self.plan, level, p)      # [C, own rows, ..]
+            keep += [m, v]
+            C, plane, row = int(p.shape[0]), int(p[0].numel()), int(p[0, 0].numel())
+            lo_own = self.plan.node_rows(level)[0]
+            splane = int(m[0].numel())
+
+            def rows(r0, r1):       # rows r0 .. r1 (inclusive) of every channel: one entry
+                o, so, n = r0 * row, (r0 - lo_own) * row, (r1 - r0 + 1) * row
+                return (entry(p.data_ptr() + 4 * o, g.data_ptr() + 4 * o, m.data_ptr() + 4 * so, v.data_ptr() + 4 * so, n, 0.01, (q_lo, 0.5), mir, off16=o,
+                              zero=True, reps=C, stride=plane, sstride=splane), 0.01)
+            (ilo, ihi), brows = stripe_row_parts(self.plan, level)
+            if ilo <= ihi:
+                interior.append(rows(ilo, ihi))
+            boundary += [rows(r, r) for r in brows]
+
+        def table(ents):
+            assert len(ents) <= _lib.NIC_ADAM_MAX_TENSORS
+            arr = (_lib.NicAdamTensor * max(len(ents), 1))(*[e for e, _ in ents])
+            return arr, [lr for _, lr in ents]
+        if self.plan is None:
+            self.table, self.table_interior = [table(grids + dec)], None
+        else:
+            self.table, self.table_interior = [table(boundary + dec)], table(interior)
+        self._keep, self._bucket = keep, gg0.data_ptr()
+
+    def _launch(self, tab, i, total_steps):
+        arr, lrs = tab
+        if not lrs:
+            return
+        cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))
+        for k, lr in enumerate(lrs):
+            arr[k].step = i + 1
+            arr[k].lr = lr * cos
+        self._lib.check(self.lib.nic_adam_multi(arr, len(lrs), 0.9, 0.999, 1e-8, self._lib.stream_ptr(self.dev)), "nic_adam_multi")
+
+    def adam_interior(self, out, i, total_steps):
+        """stripe-sharded fits: Adam over the rank's interior node rows - launched between the start of the all-reduce and its completion
+        (``stripe_exchange(overlap=)``): nothing it reads is touched by the exchange"""
+        if self.table is None or self._bucket != out.grad_g0.data_ptr():
+            self._build_table(out.grad_mlp, out.grad_g0, out.grad_g1)
+        if self.table_interior is not None:
+            self._launch(self.table_interior, i, total_steps)
 
     def adam(self, out, i, total_steps):
-        """Adam (lr 0.005 decoder / 0.01 grids, image_compression.py:361-364) x CosineAnnealingLR(T_max) + the grids' clamp: one launch
-        (two when the stripe-sharded table exceeds NIC_ADAM_MAX_TENSORS entries) - or none, when it rode on the step's reduction (fwd_bwd(adam=))"""
+        """Adam (lr 0.005 decoder / 0.01 grids, image_compression.py:361-364) x CosineAnnealingLR(T_max) + the grids' clamp: one launch - or none,
+        when it rode on the step's reduction (fwd_bwd(adam=)).  Stripe-sharded fits: the boundary rows and the decoder (after the exchange);
+        ``adam_interior`` has run under it."""
         if self._tail_done:
             self._tail_done = False
             return
         if self.table is None or self._bucket != out.grad_g0.data_ptr():
             self._build_table(out.grad_mlp, out.grad_g0, out.grad_g1)
-        cos = 0.5 * (1 + math.cos(math.pi * i / max(total_steps, 1)))
-        st = self._lib.stream_ptr(self.dev)
-        for arr, lrs in self.table:
-            for k, lr in enumerate(lrs):
-                arr[k].step = i + 1
-                arr[k].lr = lr * cos
-            self._lib.check(self.lib.nic_adam_multi(arr, len(lrs), 0.9, 0.999, 1e-8, st), "nic_adam_multi")
+        for tab in self.table:
+            self._launch(tab, i, total_steps)
         self._clean = True
 
     def n_params(self):
@@ -476,7 +510,9 @@ def run_sharded(args, rank, world, dev):
             if n_small[0] is None:
                 n_small[0] = fused.grad_bucket_layout(fused.PathGeometry(dim, method, 0.25, 0, extent, 1), *fit.grids, n_linear=fit.nl)[0][1 + 2 * fit.nl]
             small = out.flat[:n_small[0]]
-            stripe_exchange(plan, small, out.grad_g0, out.grad_g1, **({} if world > 1 else {"reduce": lambda t, g: None}))
+            # pack -> all-reduce (asynchronous on RCCL's stream) -> Adam over the interior node rows under it -> unpack -> (below) boundary rows + decoder
+            stripe_exchange(plan, small, out.grad_g0, out.grad_g1, overlap=lambda: fit.adam_interior(out, i, total_steps),
+                            **({} if world > 1 else {"reduce": lambda t, g: None}))
         else:
             all_reduce_flat(out.flat)                                 # RCCL sum of [loss | decoder grads | grid grads]
         fit.adam(out, i, total_steps)

@@ -347,6 +347,12 @@ typedef struct nic_adam_tensor {
     int32_t param16_kind;     /* 1: bfloat16, 2: IEEE half (round to nearest even) */
     int32_t flags;            /* NIC_ADAM_ZERO_GRAD: the launch also zeroes `grad` (written through the const pointer) once it has been read - the
                                  gradient bucket of an atomically accumulating step is clean for the next step without a fill kernel; 0 otherwise */
+    int32_t reps;             /* 0 / 1: one contiguous run of n elements.  r > 1: r runs of n elements each - run k starts k * rep_stride elements into
+                                 param / grad / param16 and k * state_rep_stride into exp_avg / exp_avg_sq: a block of node rows of EVERY channel of a
+                                 grid [C, rows, ..] in one entry (rep_stride = the channel plane) with moments allocated for those rows only
+                                 (state_rep_stride = n) - the stripe-owned optimiser of the multi-GPU step */
+    int32_t reserved;
+    int64_t rep_stride, state_rep_stride;
 } nic_adam_tensor;
 #define NIC_ADAM_ZERO_GRAD 1
 #define NIC_ADAM_SCHED_COL1 2 /* nic_adam_multi_dev: this tensor takes its step size from column 1 of the schedule (the decoder group), else column 0 */

@@ -73,7 +73,8 @@ class NicAdamTensor(ctypes.Structure):
     """struct nic_adam_tensor (include/nicv2_hip.h)."""
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("clamp_lo", ctypes.c_float),
-                ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("clamp_hi", ctypes.c_float), ("param16", ctypes.c_void_p), ("param16_kind", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("reps", ctypes.c_int32), ("reserved", ctypes.c_int32), ("rep_stride", ctypes.c_int64), ("state_rep_stride", ctypes.c_int64)]
 
 
 class NicStepTail(ctypes.Structure):

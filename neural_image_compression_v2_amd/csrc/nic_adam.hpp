@@ -23,6 +23,8 @@ struct AdamEntry {
     uint16_t* p16;       // optional 16-bit mirror of p (NIC_FLAG_GRID_BF16 / _FP16 storage), rewritten with the rounded new value
     int p16_kind;
     int zero_g;          // NIC_ADAM_ZERO_GRAD: the gradient is zeroed once read (an atomically accumulated bucket is clean for the next step)
+    int rep_blocks;      // blocks per run; runs of n elements rep_pg (p, g, p16) / rep_mv (m, v) elements apart (nic_adam_tensor.reps)
+    int64_t rep_pg, rep_mv;
 };
 __device__ __forceinline__ uint16_t to_store16(float x, int kind) {
     if (kind == 1) return __builtin_bit_cast(uint16_t, (__bf16)x);               // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -71,10 +73,12 @@ __device__ __forceinline__ void adam_block(const AdamTable& t, int count, int bl
     int k = 0;
     while (k + 1 < count && blk >= t.e[k + 1].first_block) ++k;
     const AdamEntry e = adam_entry(t, k);
-    const int64_t base = (int64_t)(blk - e.first_block) * kAdamChunk;
+    const int rb = blk - e.first_block, rep = rb / e.rep_blocks;
+    const int64_t base = (int64_t)(rb - rep * e.rep_blocks) * kAdamChunk;
     const int64_t left = e.n - base;
     const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
-    float* p = e.p + base; const float* g = e.g + base; float* m = e.m + base; float* v = e.v + base;
+    const int64_t base_pg = base + rep * e.rep_pg, base_mv = base + rep * e.rep_mv;
+    float* p = e.p + base_pg; const float* g = e.g + base_pg; float* m = e.m + base_mv; float* v = e.v + base_mv;
     const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
     if (vec) {
         const int n4 = cnt >> 2;
@@ -100,7 +104,7 @@ __device__ __forceinline__ void adam_block(const AdamTable& t, int count, int bl
     }
     if (e.p16 != nullptr) {                                       // the block re-reads its own chunk of the master (its own stores: visible to it)
         __syncthreads();
-        uint16_t* q = e.p16 + base;
+        uint16_t* q = e.p16 + base_pg;
         for (int i = threadIdx.x; i < cnt; i += 256) q[i] = to_store16(p[i], e.p16_kind);
     }
 }
@@ -166,14 +170,20 @@ inline int adam_build_table(const nic_adam_tensor* tensors, int count, int n_str
         e.zero_g = (a.flags & NIC_ADAM_ZERO_GRAD) ? 1 : 0;
         t.sched_col[nt - 1] = (a.flags & NIC_ADAM_SCHED_COL1) ? 1 : 0;
         if (e.p16 != nullptr && e.p16_kind != 1 && e.p16_kind != 2) return NIC_E_ARG;
+        const int64_t reps = a.reps > 1 ? a.reps : 1;
+        if (a.reps < 0 || (reps > 1 && (a.rep_stride < a.n || a.state_rep_stride < a.n))) return NIC_E_ARG;     // runs do not overlap
+        const int64_t rep_blocks = (a.n + kAdamChunk - 1) / kAdamChunk;
+        e.rep_blocks = (int)rep_blocks;
+        e.rep_pg = reps > 1 ? a.rep_stride : 0;
+        e.rep_mv = reps > 1 ? a.state_rep_stride : 0;
         if (i < n_stream) {
             e.first_block = (int)blocks;
-            blocks += (a.n + kAdamChunk - 1) / kAdamChunk;
-            if (blocks > 0x3fffffff) return NIC_E_ARG;
+            blocks += rep_blocks * reps;
+            if (rep_blocks > 0x3fffffff || blocks > 0x3fffffff) return NIC_E_ARG;
             n_stream_out = nt;
         } else {
             e.first_block = 0x7fffffff;
-            if (e.zero_g) return NIC_E_ARG;       // a decoder gradient is overwritten by the next reduction, never accumulated into
+            if (e.zero_g || reps > 1) return NIC_E_ARG;       // a decoder gradient is one contiguous tensor, overwritten by the next reduction
         }
     }
     t.count = nt;

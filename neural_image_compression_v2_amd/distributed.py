@@ -180,13 +180,20 @@ def _row_set(plan: StripePlan, level: int, grad: torch.Tensor):
 
 
 def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor, grad_g1: torch.Tensor, group=None,
-                    reduce: Optional[Callable] = None) -> None:
+                    reduce: Optional[Callable] = None, overlap: Optional[Callable] = None) -> None:
     """The exchange step of a stripe-sharded training step, in place: ``small`` (loss + decoder gradients, a 1-D view of the flat
     bucket) and the boundary node rows of the two grid gradients become sums over ranks - ONE all-reduce of
     ``small.numel() + (world - 1) * C * (row of G0 + row of G1)`` floats.  On the device the buffer is packed and unpacked by one
     launch each (``nic_stripe_pack`` / ``nic_stripe_unpack``); CPU tensors (the gloo tests with the oracle as step function) take the
-    torch formulation below."""
+    torch formulation below.
+
+    ``overlap``: work that needs NOTHING the exchange produces - the optimiser update of the rank's interior node rows
+    (``stripe_row_parts``) - called once the collective has been started and before its results are written back: on the device the
+    all-reduce is issued asynchronously (RCCL runs it on its own stream), ``overlap()`` launches onto the caller's stream meanwhile, and the
+    caller's stream only waits for the collective before the unpack.  The boundary rows and the decoder are updated by the caller afterwards."""
     if plan.world == 1:
+        if overlap is not None:
+            overlap()
         return
     if grad_g0.is_cuda and grad_g0.is_contiguous() and grad_g1.is_contiguous() and small.is_contiguous():
         import ctypes
@@ -205,7 +212,17 @@ def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor
         with torch.cuda.device(grad_g0.device):
             st = _lib.stream_ptr(grad_g0.device)
             _lib.check(lib.nic_stripe_pack(_lib.ptr(small), small.numel(), sets, 2, _lib.ptr(buf), st), "nic_stripe_pack")
-            (reduce or _all_reduce_sum)(buf, group)
+            work = None
+            if reduce is not None:
+                reduce(buf, group)
+            elif dist.get_backend(group) == "gloo":
+                _all_reduce_sum(buf, group)                               # through the host (one-GPU rehearsals): nothing to overlap with
+            else:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            if overlap is not None:
+                overlap()                                                 # interior rows: under the collective
+            if work is not None:
+                work.wait()                                               # the current stream waits for RCCL's; the host does not block
             _lib.check(lib.nic_stripe_unpack(_lib.ptr(small), small.numel(), sets, 2, _lib.ptr(buf), st), "nic_stripe_unpack")
         return
     idx0, idx1 = plan.boundary_index(grad_g0.device)
@@ -213,6 +230,8 @@ def stripe_exchange(plan: StripePlan, small: torch.Tensor, grad_g0: torch.Tensor
     ns, n0 = small.numel(), h0.numel()
     buf = torch.cat([small.reshape(-1), h0.reshape(-1), h1.reshape(-1)])
     (reduce or _all_reduce_sum)(buf, group)                                 # `reduce`: test / rehearsal hook
+    if overlap is not None:
+        overlap()                                                           # before the sums are written back: it must not need them
     small.copy_(buf[:ns].view_as(small))
     grad_g0.index_copy_(1, idx0, buf[ns:ns + n0].view_as(h0))
     grad_g1.index_copy_(1, idx1, buf[ns + n0:].view_as(h1))
@@ -226,6 +245,18 @@ def stripe_param_blocks(plan: StripePlan, level: int, *tensors: torch.Tensor) ->
     the whole tensors and relied on zero gradients AND zero moments outside the stripe)."""
     lo, hi = plan.node_rows(level)
     return [tuple(t[c, lo:hi + 1] for t in tensors) for c in range(tensors[0].shape[0])]
+
+
+def stripe_row_parts(plan: StripePlan, level: int) -> Tuple[Tuple[int, int], List[int]]:
+    """The rank's node rows of grid ``level`` split for the overlapped step: ``((lo, hi), boundary)`` - the inclusive range of INTERIOR rows
+    (touched by this rank's samples only: their gradients are final when the fused kernel ends; ``lo > hi`` when there are none) and the
+    rank's boundary rows (shared with a neighbour: final after the exchange) - at most two, the first and / or last row of its stripe."""
+    lo, hi = plan.node_rows(level)
+    shared = set(plan.boundary_rows(level))
+    boundary = [r for r in (lo, hi) if r in shared]
+    if lo == hi:
+        boundary = boundary[:1]
+    return (lo + (1 if lo in shared else 0), hi - (1 if hi in shared else 0)), boundary
 
 
 def stripe_state(plan: StripePlan, level: int, grid: torch.Tensor) -> torch.Tensor:

@@ -235,3 +235,92 @@ def test_host_loop_trains_identically_with_and_without_the_tail(dev, flags):
         assert relmax(b, a) < 5e-3, relmax(b, a)
     print(f"\nPSNR after 50 steps: tail {g['psnr']:.4f} dB, separate launches {h['psnr']:.4f} dB; largest loss difference {rel:.1e}")
     assert abs(h["psnr"] - g["psnr"]) < 0.02
+
+
+def test_row_block_entries_are_the_per_channel_blocks(dev):
+    """nic_adam_tensor.reps (the stripe-owned optimiser of the multi-GPU step): ONE entry covering node rows r0 .. r1 of every channel of a grid
+    [C, rows, X], moments allocated for those rows only, against one contiguous entry per channel (what round 3 launched): identical parameters,
+    moments, 16-bit mirror and zeroed gradient rows; everything outside the rows untouched"""
+    from neural_image_compression_v2_amd import _lib
+    lib = _lib.load()
+    C, R, X, r0, r1 = 12, 37, 501, 5, 29                                     # odd sizes: unaligned runs take the scalar path, chunks end mid-run
+    g = torch.Generator().manual_seed(2)
+    res = {}
+    for mode in ("per-channel", "reps"):
+        p = (torch.rand(C, R, X, generator=g.manual_seed(2)) - 0.5).to(dev)
+        gr = (torch.rand(C, R, X, generator=g.manual_seed(3)) - 0.5).to(dev) * 1e-3
+        mir = p.to(torch.bfloat16)
+        n_own = r1 - r0 + 1
+        m = (torch.rand(C, n_own, X, generator=g.manual_seed(4)) * 1e-4).to(dev)
+        v = (torch.rand(C, n_own, X, generator=g.manual_seed(5)) * 1e-8).to(dev)
+        q_lo = -(2 ** 8 - 1) / 2 ** 9
+        if mode == "reps":
+            o = r0 * X
+            arr = (_lib.NicAdamTensor * 1)(_lib.NicAdamTensor(p.data_ptr() + 4 * o, gr.data_ptr() + 4 * o, m.data_ptr(), v.data_ptr(), n_own * X, 7, 0.01, q_lo, 0.5,
+                                                              mir.data_ptr() + 2 * o, 1, _lib.NIC_ADAM_ZERO_GRAD, C, 0, R * X, n_own * X))
+        else:
+            arr = (_lib.NicAdamTensor * C)(*[_lib.NicAdamTensor(p[c, r0:r1 + 1].data_ptr(), gr[c, r0:r1 + 1].data_ptr(), m[c].data_ptr(), v[c].data_ptr(), n_own * X, 7,
+                                                                 0.01, q_lo, 0.5, mir[c, r0:r1 + 1].data_ptr(), 1, _lib.NIC_ADAM_ZERO_GRAD) for c in range(C)])
+        _lib.check(lib.nic_adam_multi(arr, len(arr), 0.9, 0.999, 1e-8, _lib.stream_ptr(dev)), "nic_adam_multi")
+        torch.cuda.synchronize()
+        res[mode] = (p.clone(), gr.clone(), m.clone(), v.clone(), mir.clone())
+    for a, b, what in zip(res["per-channel"], res["reps"], ("parameters", "gradients", "exp_avg", "exp_avg_sq", "mirror")):
+        assert torch.equal(a, b), what
+    p, gr, m, v, mir = res["reps"]
+    p_start = (torch.rand(C, R, X, generator=g.manual_seed(2)) - 0.5).to(dev)
+    assert torch.equal(p[:, :r0], p_start[:, :r0]) and torch.equal(p[:, r1 + 1:], p_start[:, r1 + 1:])          # rows outside: untouched
+    assert not torch.equal(p[:, r0:r1 + 1], p_start[:, r0:r1 + 1])
+    assert float(gr[:, r0:r1 + 1].abs().max()) == 0.0 and float(gr[:, :r0].abs().min()) >= 0.0 and float(gr[:, :r0].abs().max()) > 0.0
+    assert torch.equal(mir[:, r0:r1 + 1], p[:, r0:r1 + 1].to(torch.bfloat16))
+    # malformed runs are refused on the host
+    bad = (_lib.NicAdamTensor * 1)(_lib.NicAdamTensor(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n_own * X, 1, 0.01, 1.0, -1.0, 0, 0, 0, C, 0, 10, n_own * X))
+    assert lib.nic_adam_multi(bad, 1, 0.9, 0.999, 1e-8, _lib.stream_ptr(dev)) < 0                               # runs overlap
+
+
+def test_virtual_world_stripe_step_equals_whole_block_adam(dev):
+    """the bench's stripe-sharded step (rank 0 of a virtual 4-rank world, strong scaling): interior rows under the exchange + boundary rows and decoder
+    after it, in two launches, against ONE nic_adam_multi over the rank's whole row blocks - the same update of every own row"""
+    import bench
+    from neural_image_compression_v2_amd import _lib, fused
+    from neural_image_compression_v2_amd.distributed import plan_stripes, stripe_exchange, stripe_param_blocks, stripe_state
+    Hh, Ww = 128, 512
+    res = {}
+    for mode in ("split", "whole"):
+        fit = bench.Fit(dev, 2, 1, grid_base=(Hh // 4, Ww // 4), precision="split", seed=3)
+        plan = plan_stripes(Ww, 8, 1, 4)                                    # an inner rank: boundary rows on both sides
+        fit.plan = plan
+        extent = (Hh, plan.size)
+        org = torch.tensor([[0, plan.start]], dtype=torch.int32, device=dev)
+        target = torch.rand(Hh * plan.size, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+        for i in range(3):
+            out = fit.fwd_bwd(fit.geometry(i, extent, 1, 1, Hh * plan.start, Hh * Ww), org, target)
+            n_small = fused.grad_bucket_layout(fused.PathGeometry(2, 1, 0.25, 0, extent, 1), *fit.grids, n_linear=3)[0][7]
+            if mode == "split":
+                stripe_exchange(plan, out.flat[:n_small], out.grad_g0, out.grad_g1, overlap=lambda: fit.adam_interior(out, i, 10), reduce=lambda t, g: None)
+                fit.adam(out, i, 10)
+            else:
+                stripe_exchange(plan, out.flat[:n_small], out.grad_g0, out.grad_g1, reduce=lambda t, g: None)
+                if i == 0:
+                    st = [(stripe_state(plan, lv, p), stripe_state(plan, lv, p)) for lv, p in enumerate(fit.master)]
+                    dm = [(torch.zeros_like(p), torch.zeros_like(p)) for p in fit.params]
+                ents = []
+                q_lo = -(2 ** 8 - 1) / 2 ** 9
+                cos = 0.5 * (1 + np.cos(np.pi * i / 10))
+                for lv, (p, gq) in enumerate(zip(fit.master, (out.grad_g0, out.grad_g1))):
+                    for c, (pb, gb) in enumerate(stripe_param_blocks(plan, lv, p, gq)):
+                        ents.append(_lib.NicAdamTensor(pb.data_ptr(), gb.data_ptr(), st[lv][0][c].data_ptr(), st[lv][1][c].data_ptr(), pb.numel(), i + 1, 0.01 * cos,
+                                                       q_lo, 0.5, 0, 0, _lib.NIC_ADAM_ZERO_GRAD))
+                for (p, gq), (m_, v_) in zip(zip(fit.params, out.grad_mlp), dm):
+                    ents.append(_lib.NicAdamTensor(p.data_ptr(), gq.data_ptr(), m_.data_ptr(), v_.data_ptr(), p.numel(), i + 1, 0.005 * cos, 1.0, -1.0))
+                arr = (_lib.NicAdamTensor * len(ents))(*ents)
+                _lib.check(fit.lib.nic_adam_multi(arr, len(ents), 0.9, 0.999, 1e-8, _lib.stream_ptr(dev)), "nic_adam_multi")
+                fit._clean = True
+        torch.cuda.synchronize()
+        res[mode] = [p.clone() for p in fit.master + fit.params]
+    for i, (a, b) in enumerate(zip(res["split"], res["whole"])):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err <= 5e-5, (i, err)                                        # atomic order of the grid gradients only (three steps of Adam on top)
+    lo, hi = plan.node_rows(0)
+    fresh = bench.Fit(dev, 2, 1, grid_base=(Hh // 4, Ww // 4), precision="split", seed=3)
+    assert torch.equal(res["split"][0][:, :lo], fresh.master[0][:, :lo]) and torch.equal(res["split"][0][:, hi + 1:], fresh.master[0][:, hi + 1:])   # node rows = tensor axis 1
+    assert not torch.equal(res["split"][0][:, lo:hi + 1], fresh.master[0][:, lo:hi + 1])

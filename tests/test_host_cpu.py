@@ -439,14 +439,17 @@ def test_bench_multi_gpu_workloads_launch(extra, key, want):
     assert rec["n_gpus"] == 3 and rec["rank_sum"] == 3.0 and rec[key] == want, rec
 
 
-def _video_stripe_worker(rank, world, port, out_path):
-    """3D field, z-stripes, STRONG scaling (one pass over the field split over the ranks), Adam over the rank's own node rows only"""
+def _video_stripe_worker(rank, world, port, out_path, overlapped=False):
+    """3D field, z-stripes, STRONG scaling (one pass over the field split over the ranks), Adam over the rank's own node rows only;
+    ``overlapped``: the interior rows are updated from inside ``stripe_exchange(overlap=)`` - before the sums are written back - and only the
+    boundary rows afterwards (the ordering of the multi-GPU bench step)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sys.path.insert(0, ROOT)
         from neural_image_compression_v2_amd import _lib, fused
-        from neural_image_compression_v2_amd.distributed import assemble_stripes, plan_stripes, stripe_exchange, stripe_param_blocks, stripe_state
+        from neural_image_compression_v2_amd.distributed import (assemble_stripes, plan_stripes, stripe_exchange, stripe_param_blocks, stripe_row_parts,
+                                                                     stripe_state)
         from oracle import nic_oracle as O
         torch.set_num_threads(2)
         ext = (8, 8, 32)                                             # sample axes (x, y, z); z is the stripe axis (tensor axis 1 of [C, Z, Y, X])
@@ -465,17 +468,42 @@ def _video_stripe_worker(rank, world, port, out_path):
         tgt = field[:, :, plan.start:plan.start + plan.size].reshape(-1, 3)
         out = _oracle_step(geo_of(local, ext[0] * ext[1] * plan.start), g0, g1, torch.tensor([[0, 0, plan.start]]), mlp.tensors(), tgt)
         offs, sizes, _ = fused.grad_bucket_layout(geo_of(local, 0), g0, g1)
-        stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)
         # "Adam" stand-in with state: p -= 0.5 * (grad + m), moments start NON-ZERO outside the stripe too - only the own rows may move
         moved = []
-        for level, (p, gr) in enumerate(((g0, out.grad_g0), (g1, out.grad_g1))):
-            before = p.clone()
-            m = stripe_state(plan, level, p) + 0.25                  # a resumed state: non-zero moments
-            for c, (pb, gb) in enumerate(stripe_param_blocks(plan, level, p, gr)):
-                assert pb.is_contiguous() and gb.is_contiguous() and pb.shape == m[c].shape
-                pb -= 0.5 * (gb + m[c])
+        levels = ((g0, out.grad_g0), (g1, out.grad_g1))
+        befores = [p.clone() for p, _ in levels]
+        if not overlapped:
+            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1)
+            for level, (p, gr) in enumerate(levels):
+                m = stripe_state(plan, level, p) + 0.25              # a resumed state: non-zero moments
+                for c, (pb, gb) in enumerate(stripe_param_blocks(plan, level, p, gr)):
+                    assert pb.is_contiguous() and gb.is_contiguous() and pb.shape == m[c].shape
+                    pb -= 0.5 * (gb + m[c])
+        else:
+            def rows_update(level, r0, r1):
+                p, gr = levels[level]
+                if r0 <= r1:
+                    p[:, r0:r1 + 1] -= 0.5 * (gr[:, r0:r1 + 1] + 0.25)
+            parts = [stripe_row_parts(plan, level) for level in (0, 1)]
+            for level in (0, 1):                                     # the split tiles the own rows exactly
+                (ilo, ihi), brows = parts[level]
+                lo, hi = plan.node_rows(level)
+                assert sorted(list(range(ilo, ihi + 1)) + brows) == list(range(lo, hi + 1))
+                assert all(r in plan.boundary_rows(level) for r in brows) and not any(r in plan.boundary_rows(level) for r in range(ilo, ihi + 1))
+            snap = [gr.clone() for _, gr in levels]
+
+            def interior():
+                # called with the collective in flight: the gradients of the interior rows are already final (nothing of the exchange is in yet)
+                assert all(torch.equal(a, gr) for a, (_, gr) in zip(snap, levels))
+                for level in (0, 1):
+                    rows_update(level, *parts[level][0])
+            stripe_exchange(plan, out.flat[:offs[7]], out.grad_g0, out.grad_g1, overlap=interior)
+            for level in (0, 1):
+                for r in parts[level][1]:
+                    rows_update(level, r, r)                         # boundary rows: with the summed gradients
+        for level, (p, _) in enumerate(levels):
             lo, hi = plan.node_rows(level)
-            moved.append(float((p - before)[:, :lo].abs().sum() + (p - before)[:, hi + 1:].abs().sum()))
+            moved.append(float((p - befores[level])[:, :lo].abs().sum() + (p - befores[level])[:, hi + 1:].abs().sum()))
         assemble_stripes(plan, g0, g1)
         # single process: the same voxels as the ranks' stripes in rank order, global sample ids
         plans = [plan_stripes(ext[2], 8, r, world) for r in range(world)]
@@ -514,6 +542,21 @@ def test_video_stripes_strong_scaling_and_stripe_owned_adam_gloo():
             assert res["moved_outside"] == 0.0, res
             assert res["small"] < 1e-6 and res["p0"] < 1e-6 and res["p1"] < 1e-6, (r, res)
             assert res["whole_loss"] < 1e-6 and res["whole_g0"] < 1e-5, (r, res)
+
+
+def test_overlapped_stripe_step_matches_single_process_gloo():
+    """the overlapped ordering of the stripe-sharded step - exchange started, the optimiser over the INTERIOR node rows
+    while it is in flight (their gradients must already be final: the callback sees the un-exchanged bucket), the boundary rows after it - gives
+    the single-process update on every rank; the interior / boundary split tiles a rank's own rows exactly"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.pt")
+        mp.spawn(_video_stripe_worker, args=(2, port, out, True), nprocs=2, join=True)
+        for r in range(2):
+            res = torch.load(out + f".{r}")
+            assert res["moved_outside"] == 0.0, res
+            assert res["small"] < 1e-6 and res["p0"] < 1e-6 and res["p1"] < 1e-6, (r, res)
 
 
 def test_counter_based_sampler_host_functions_match_the_oracle(lib):
