@@ -558,6 +558,33 @@ def run_sharded(args, rank, world, dev):
                 m.copy_(p)
     timed_kernel_ms = [e.elapsed_ms() for e in ev]                     # the fused kernel alone (nic_mark_kernel_end)
     kern_ms = float(np.mean(timed_kernel_ms))
+    # the OTHER shard leg of the same strong-scaling step, same run, same timing protocol: replicated parameters, the whole gradient bucket
+    # all-reduced (the north star's literal scheme; `--shard replicated` makes it the headline leg instead) - so that one line carries both
+    other_leg = None
+    if world > 1 and strong and stripes and not video:
+        f2 = Fit(dev, dim, method, grid_base=tuple(s // 4 for s in full), n_linear=args.decoder, precision=args.precision, grid_dtype=gdt)
+
+        def step2(i):
+            o = f2.fwd_bwd(f2.geometry(i, extent, 1, 1, base_mine, n_global), org, target)
+            all_reduce_flat(o.flat)
+            f2.adam(o, i, total_steps)
+        for i in range(3):
+            step2(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            step2(3 + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e2 = float(tt.item())
+        other_leg = {"shard": "replicated", "ms_per_step": round(e2 / args.steps * 1e3, 4), "value": round(n_domain * args.steps / e2 / 1e6, 2),
+                     "all_reduce_bytes_per_step": int(f2.flat.numel()) * 4, "steps": args.steps, "warmup": 3}
+        del f2
     psnr = None
     if not video:
         # the metric's "+ PSNR" (outside the timed region): decode the whole image with the current parameters, PSNR with peak 2^8
@@ -647,6 +674,9 @@ def run_sharded(args, rank, world, dev):
         }
         if psnr is not None:
             res["config"]["psnr_db_after_these_steps"] = round(psnr, 3)
+        if other_leg is not None:
+            res["shard_legs"] = {"stripes": {"ms_per_step": res["ms_per_step"], "value": res["value"]}, "replicated": other_leg,
+                                 "note": "`value` is the stripes leg; both legs ran in this process group, back to back"}
         nodes = [int(g[0].numel()) for g in fit.master]
         res["roofline"] = roofline_record(dim, method, args.precision, fit.nl, kern_ms, n_mine, traffic,
                                           {"timed_steps": pct(timed_kernel_ms), **({"stat_leg": pct(stat_main)} if stat_main else {})}, gb, nodes)
