@@ -696,7 +696,7 @@ def _ml_geo_desc(geo: PathGeometry, fp, coord) -> "_lib.NicPathDesc":
 @_on_tensor_device
 def fused_ml_forward_backward(geo: PathGeometry, fp: Sequence[torch.Tensor], coord, params, target: torch.Tensor, noise: Optional[torch.Tensor] = None,
                               want_y: bool = False, grads: Optional[Sequence[torch.Tensor]] = None, mlp_grads: Optional[Sequence[torch.Tensor]] = None,
-                              loss: Optional[torch.Tensor] = None, events=None) -> MlStepOutput:
+                              loss: Optional[torch.Tensor] = None, events=None, tail=None) -> MlStepOutput:
     """One multi-level training step in ONE launch (+ the fixed-order reduction of the decoder-gradient records): ``geo`` describes pair 0
     (``step_number`` = 2^(mip - 2): pair l runs at 4^-l of it), ``fp`` = [G0_0, G1_0, G0_1, G1_1, ..] fp32 grids.  ``grads`` (one fp32 tensor per grid) are
     ADDED to when given - a whole-image pass walked in chunks - and freshly zeroed otherwise; decoder gradients and the loss are overwritten.
@@ -727,11 +727,15 @@ def fused_ml_forward_backward(geo: PathGeometry, fp: Sequence[torch.Tensor], coo
     lib = _lib.load()
     ws = _lib.workspace(dev, int(lib.nic_workspace_bytes(ctypes.byref(d))))
     m, gs = _mlp_struct(params), _grads_struct(mlp_grads)
+    if tail is not None:                       # optim.StepTail on `grads` / `mlp_grads`: the optimiser step rides on the reduction launch
+        d.tail = tail.struct_ptr
     if events is not None:
         events[0].record(torch.cuda.current_stream(dev))
     _lib.check(lib.nic_fused_ml_forward_backward(ctypes.byref(d), ctypes.byref(pr), _lib.ptr(org), ctypes.byref(m),
                                                  _lib.ptr(noise if geo.noise_mode == NIC_NOISE_TENSOR else None), _lib.ptr(target), _lib.ptr(y), _lib.ptr(loss),
                                                  ctypes.byref(gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "nic_fused_ml_forward_backward")
+    if tail is not None:
+        tail.commit()
     if events is not None:
         events[1].record(torch.cuda.current_stream(dev))
     return MlStepOutput(loss[0], y, list(grads), list(mlp_grads))

@@ -25,6 +25,8 @@ Hashed indexing is not built: the reference's grids are dense and so are these (
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -150,7 +152,11 @@ class MultiLevelField:
         if not accumulate and not getattr(self, "_grid_grads_clean", False):
             for g in gfp:
                 g.zero_()
-        out = fused.fused_ml_forward_backward(geo, self.fp, coord, params, target, grads=gfp, mlp_grads=gtmp if accumulate else gmlp, loss=self._loss)
+        tail = None
+        if step and not accumulate and isinstance(self.optimizer, FusedAdam) and os.environ.get("NIC_NO_TAIL") != "1":
+            # a whole step in this launch: the optimiser rides on the reduction of the decoder records (nic_path_desc.tail) - two launches per step
+            tail = self.optimizer.step_tail(list(zip(self.fp, gfp)), list(zip(params, gmlp)))
+        out = fused.fused_ml_forward_backward(geo, self.fp, coord, params, target, grads=gfp, mlp_grads=gtmp if accumulate else gmlp, loss=self._loss, tail=tail)
         if accumulate:
             for a, b in zip(gmlp, gtmp):
                 a.add_(b)

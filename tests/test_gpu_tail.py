@@ -324,3 +324,48 @@ def test_virtual_world_stripe_step_equals_whole_block_adam(dev):
     fresh = bench.Fit(dev, 2, 1, grid_base=(Hh // 4, Ww // 4), precision="split", seed=3)
     assert torch.equal(res["split"][0][:, :lo], fresh.master[0][:, :lo]) and torch.equal(res["split"][0][:, hi + 1:], fresh.master[0][:, hi + 1:])   # node rows = tensor axis 1
     assert not torch.equal(res["split"][0][:, lo:hi + 1], fresh.master[0][:, lo:hi + 1])
+
+
+def test_multilevel_step_with_and_without_the_tail(dev):
+    """the fused multi-level step (nic_fused_ml_forward_backward, 3 level pairs): whole steps ride the optimiser on the reduction launch, steps walked
+    in chunks (gradients accumulated over launches) keep the separate optimiser launch - 30 mixed steps with the tail and with NIC_NO_TAIL=1 give the
+    same loss history and the same parameters to the order of the atomic sums"""
+    from neural_image_compression_v2_amd.multilevel import MultiLevelField
+    S = (256, 192)
+    u, w = torch.linspace(0, 1, S[0]), torch.linspace(0, 1, S[1])
+    tgt = torch.stack([0.5 + 0.4 * torch.sin(6.28 * (c + 1) * u)[:, None] * torch.cos(6.28 * (c + 2) * w)[None, :] for c in range(3)], dim=-1).to(dev)
+    res = {}
+    old = os.environ.get("NIC_NO_TAIL")
+    try:
+        for mode in ("tail", "separate"):
+            if mode == "separate":
+                os.environ["NIC_NO_TAIL"] = "1"
+            else:
+                os.environ.pop("NIC_NO_TAIL", None)
+            f = MultiLevelField(S, 3, channels=4, hidden=64, n_linear=3, device=dev, seed=0, fused_step=True)
+            f.set_schedule(30)
+            losses = []
+            for step in range(30):
+                if step % 3 != 2:
+                    losses.append(float(f.train_step([[0, 0]], S, tgt.reshape(-1, 3))))
+                else:
+                    tot = 0.0
+                    for k, x0 in enumerate((0, 128)):
+                        tot += float(f.train_step([[x0, 0]], (128, 192), tgt[x0:x0 + 128].reshape(-1, 3), accumulate=k > 0, scale=0.5, step=k == 1))
+                    losses.append(tot)
+            torch.cuda.synchronize()
+            assert (getattr(f.optimizer, "_tail_cache", None) is not None) == (mode == "tail")
+            assert {int(f.optimizer.state[p]["step"].item()) for p in f.optimizer.state} == {30}
+            res[mode] = (losses, [p.detach().clone() for p in list(f.fp) + list(f.decoder.linear_params())])
+    finally:
+        if old is None:
+            os.environ.pop("NIC_NO_TAIL", None)
+        else:
+            os.environ["NIC_NO_TAIL"] = old
+    (la, pa), (lb, pb) = res["tail"], res["separate"]
+    assert lb[-1] < 0.5 * lb[0]
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-3 * abs(y), (x, y)
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        err = float((x - y).abs().max() / y.abs().max())
+        assert err <= 5e-3, (i, err)
