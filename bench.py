@@ -252,6 +252,8 @@ class KernelEvents:
     right before the entry point, `end` by the library right after its fused kernel - before the reduction / optimiser-tail launch
     (nic_mark_kernel_end).  Drop-in for the (torch.cuda.Event, torch.cuda.Event) pairs ``fused_forward_backward(events=)`` records."""
     _hip = None
+    _inflight = []                 # pairs recorded and not yet waited for, oldest first
+    MAX_INFLIGHT = 16              # the host stays at most this many timed steps ahead of the GPU (a bounded number of recorded-but-unfinished events)
 
     def __init__(self, lib):
         if KernelEvents._hip is None:
@@ -270,6 +272,10 @@ class KernelEvents:
         def record(self, stream):
             if self.first:
                 o = self.owner
+                q = KernelEvents._inflight
+                if len(q) >= KernelEvents.MAX_INFLIGHT:
+                    KernelEvents._hip.hipEventSynchronize(q.pop(0).e[1])
+                q.append(o)
                 if KernelEvents._hip.hipEventRecord(o.e[0], ctypes.c_void_p(stream.cuda_stream)) != 0:
                     raise RuntimeError("hipEventRecord failed")
                 o.lib.nic_mark_kernel_end(o.e[1])
@@ -278,6 +284,8 @@ class KernelEvents:
         return KernelEvents._Rec(self, i == 0)
 
     def elapsed_ms(self) -> float:
+        if self in KernelEvents._inflight:
+            KernelEvents._inflight.remove(self)
         ms = ctypes.c_float()
         if KernelEvents._hip.hipEventElapsedTime(ctypes.byref(ms), self.e[0], self.e[1]) != 0:
             raise RuntimeError("hipEventElapsedTime failed (an event was never recorded)")
@@ -310,6 +318,7 @@ class Fit:
         self._clean = False                                           # True: the grid-gradient part of the bucket is known to be zero
         self._tail_done = False
         self._tail_obj = None
+        self._plans, self._orgs = {}, {}
         self.plan = None                                              # StripePlan: Adam over this rank's node rows only
 
     @property
@@ -329,10 +338,29 @@ class Fit:
         per step; the caller's ``adam(out, i, total_steps)`` that follows then launches nothing.  (Stripe-sharded fits exchange gradients between
         the two: their optimiser stays a launch of its own.)"""
         g0, g1 = self.grids
-        tail = None
-        if adam is not None and self.plan is None and os.environ.get("NIC_NO_TAIL") != "1":
-            tail = lambda gg0, gg1, gm: self._tail(gg0, gg1, gm, *adam)
-        out = self.fused.fused_forward_backward(geo, g0, g1, org, self.params, target, flat=self.flat, events=events, tail=tail, clean=self._clean)
+        use_tail = adam is not None and self.plan is None and os.environ.get("NIC_NO_TAIL") != "1"
+        if geo.noise_mode != self._lib.NIC_NOISE_TENSOR and os.environ.get("NIC_NO_PLAN") != "1":
+            # the steady state of a loop: one prepared launch per (shape, arithmetic, target) - fused.StepPlan, what the host loop of
+            # ImageCompression.train_models uses: descriptor, parameter structs, gradient bucket and workspace are built once, a step rewrites
+            # the noise offset and launches (the general wrapper re-validates everything per call: ~ 60 us of Python, more than a small step's GPU time)
+            if not isinstance(org, torch.Tensor):
+                okey = tuple(tuple(int(v) for v in o) for o in org)
+                if okey not in self._orgs:
+                    host = torch.tensor(okey, dtype=torch.int64).reshape(-1, geo.dim)
+                    self.fused.check_origins(geo, host, g0, g1)
+                    self._orgs[okey] = host.to(torch.int32).to(self.dev)
+                org = self._orgs[okey]
+            key = (tuple(geo.extent), geo.num_crops, geo.passes, geo.sample_base, geo.loss_scale, geo.flags, geo.split_bf16, geo.bf16, geo.fp16,
+                   geo.dz_scale_log2, id(target), g0.data_ptr())
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = self._plans[key] = self.fused.StepPlan(geo, g0, g1, self.params, target)
+            tail = self._tail(plan.gg0, plan.gg1, plan.gm, *adam) if use_tail else None
+            plan.clean = self._clean and self.flat is plan.flat       # the optimiser zeroed what it read of THIS bucket (NIC_ADAM_ZERO_GRAD)
+            out = plan.run(org, geo.noise_mode, geo.noise_seed, geo.noise_offset, tail=tail, events=events)
+        else:
+            tail = (lambda gg0, gg1, gm: self._tail(gg0, gg1, gm, *adam)) if use_tail else None
+            out = self.fused.fused_forward_backward(geo, g0, g1, org, self.params, target, flat=self.flat, events=events, tail=tail, clean=self._clean)
         self.flat = out.flat
         self._clean = False
         if self._tail_done:
@@ -799,6 +827,13 @@ def main():
         ap.error("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # no cyclic-GC pauses inside timed regions: with torch imported a generation-2 collection takes 40-50 ms of host time - invisible behind 2 ms steps
+    # (the GPU has work queued), a 3 x error on a 40-step loop of 0.4 ms steps (measured at call 41 of `--workload vol128`; ab/dbg/stall_dbg.py).  The
+    # process is short-lived and its steady state allocates no cycles worth collecting.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -18,6 +18,7 @@ records are kept under profiles/.
 """
 import json
 import math
+import os
 import time
 
 import numpy as np
@@ -97,10 +98,15 @@ def _run_volume(args, dev, name, dim, method, extent, grid_base, origin, split=T
     torch.cuda.synchronize()
     ev = [bench.KernelEvents(fit.lib) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    trace = [t0]
     for i in range(args.steps):
         out = step(args.warmup + i, ev[i])
+        trace.append(time.perf_counter())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    if os.environ.get("NIC_BENCH_TRACE") == "1":
+        import sys
+        print("host ms per step:", " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip(trace, trace[1:])), f"| total {(time.perf_counter() - t0) * 1e3:.1f}", file=sys.stderr)
     kms = [e.elapsed_ms() for e in ev]
     gb = 4 if fit.mirror is None else 2
     cin, flop, byt = bench.work_per_sample(dim, method, args.decoder, gb)

@@ -188,9 +188,11 @@ __device__ __forceinline__ void gelu_sig4(const f32x4_t z, f32x4_t& a, f32x4_t& 
             q = pk_fma(f32x2(-3.f * LN2 * C1), x2, f32x2(-LN2 * C0));
         }
         const f32x2 u = x * w;
+        f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};   // 2^u = inf -> Phi = 0; 2^u = 0 -> Phi = 1
+        e = e + f32x2(1.0f);                                                       // one v_pk_add_f32 (the scalar form compiles to two v_add_f32)
         f32x2 P;
-        P[0] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[0]));         // 2^u = inf -> Phi = 0; 2^u = 0 -> Phi = 1
-        P[1] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[1]));
+        P[0] = __builtin_amdgcn_rcpf(e[0]);
+        P[1] = __builtin_amdgcn_rcpf(e[1]);
         const f32x2 av = x * P;
         const f32x2 dv = pk_fma(av * (f32x2(1.0f) - P), q, P);
         a[2 * i] = av[0]; a[2 * i + 1] = av[1];

@@ -529,13 +529,16 @@ class StepPlan:
     """``fused_forward_backward`` for a training loop: everything that does not change from step to step - the checked grids and
     decoder parameters, the descriptor, the gradient bucket and its views, the parameter / gradient structs - is prepared once; ``run`` rewrites the noise fields and the origins and launches.  The Python side
     of a step drops from ~60 to ~15 us (the reference's default step is host-bound: 8 x 256^2 samples take the GPU 0.21 ms).
-    Targets: a resident :class:`TargetImage`.  Origins: a host tensor / list (validated) or a device int32 tensor (taken as is)."""
+    Targets: a resident :class:`TargetImage`, or a resident fp32 ``[N, 3]`` tensor (the reference's crop stack, image_compression.py:37-47; the same rows
+    every step - whole-domain passes).  Origins: a host tensor / list (validated) or a device int32 tensor (taken as is)."""
 
     LOSS_SLOTS = 1 << 16
 
-    def __init__(self, geo: PathGeometry, g0, g1, params, target: "TargetImage"):
+    def __init__(self, geo: PathGeometry, g0, g1, params, target):
         if not isinstance(target, TargetImage):
-            raise TypeError("StepPlan reads its targets from a resident TargetImage")
+            target = _lib.require_cuda_f32(target, "target").reshape(-1, 3)
+            if target.shape[0] != geo.n_samples:
+                raise ValueError(f"target has {target.shape[0]} rows, geometry has {geo.n_samples} samples")
         self.geo = geo
         self.g0 = _lib.require_cuda_grid(grid_storage(g0).detach(), "G0")
         self.g1 = _lib.require_cuda_grid(grid_storage(g1).detach(), "G1")
@@ -562,18 +565,22 @@ class StepPlan:
             self.d.hidden = FUSED_HIDDEN
         self.m = self.pad.m if self.pad is not None else _mlp_struct(self.params)
         self.gs = self.pad.gs if self.pad is not None else _grads_struct(self.gm)
-        self.timg = target.to_struct(geo, [[0] * geo.dim] * geo.num_crops)
+        self.timg = target.to_struct(geo, [[0] * geo.dim] * geo.num_crops) if isinstance(target, TargetImage) else None
         self.target = target
         self.lib = _lib.load()
         self.n_org = geo.num_crops * geo.dim
         # host-side bounds of a valid origin (check_origins + TargetImage.to_struct, per axis)
         self.hi = []
-        sp = target.spatial
+        sp = target.spatial if self.timg is not None else None
         for a in range(geo.dim):
             s = float(geo.step_number)
             n0, n1 = int(self.g0.shape[-(a + 1)]), int(self.g1.shape[-(a + 1)])
-            hi = int(sp[a]) - int(geo.extent[a])
-            while hi >= 0 and (math.floor((hi + int(geo.extent[a]) - 1) * s) + 1 > n0 - 1 or math.floor((hi + int(geo.extent[a]) - 1) * s / 2) + 1 > n1 - 1):
+            ext = int(geo.extent[a])
+            if sp is not None:
+                hi = int(sp[a]) - ext
+            else:                                     # no image: the grids bound the origin (last sample t: floor(t s) + 1 <= n0 - 1, floor(t s / 2) + 1 <= n1 - 1)
+                hi = min(math.ceil((n0 - 1) / s), math.ceil((n1 - 1) * 2 / s)) - ext
+            while hi >= 0 and (math.floor((hi + ext - 1) * s) + 1 > n0 - 1 or math.floor((hi + ext - 1) * s / 2) + 1 > n1 - 1):
                 hi -= 1
             self.hi.append(hi)
 
@@ -581,7 +588,7 @@ class StepPlan:
         return (grid_storage(g0).data_ptr() == self.g0.data_ptr() and grid_storage(g1).data_ptr() == self.g1.data_ptr() and target is self.target
                 and len(params) == len(self.params) and all(p.data_ptr() == q.data_ptr() for p, q in zip(params, self.params)))
 
-    def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int, tail=None) -> StepOutput:
+    def run(self, coord, noise_mode: int, noise_seed: int, noise_offset: int, tail=None, events=None) -> StepOutput:
         """``tail``: an ``optim.StepTail`` built on this plan's buffers (``FusedAdam.step_tail([(g0, plan.gg0), (g1, plan.gg1)], zip(params, plan.gm))``):
         the optimiser step rides on the reduction launch; committed here once the launch is queued"""
         geo, dev = self.geo, self.dev
@@ -617,13 +624,23 @@ class StepPlan:
                 self.pad.pad()
                 tail = None                  # zero-padded decoders reduce into padded copies: their step stays a launch of its own
             d.tail = tail.struct_ptr if tail is not None else None
+            if events is not None:           # (start, end) event pair recorded on the launch stream (bench.KernelEvents brackets the fused kernel alone)
+                events[0].record(torch.cuda.current_stream(dev))
             try:
-                _lib.check(self.lib.nic_fused_forward_backward_img(
-                    ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
-                    self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
-                    "nic_fused_forward_backward_img")
+                if self.timg is not None:
+                    _lib.check(self.lib.nic_fused_forward_backward_img(
+                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
+                        self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                        "nic_fused_forward_backward_img")
+                else:
+                    _lib.check(self.lib.nic_fused_forward_backward(
+                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, _lib.ptr(self.target), None,
+                        self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                        "nic_fused_forward_backward")
             finally:
                 d.tail = None
+            if events is not None:
+                events[1].record(torch.cuda.current_stream(dev))
             if tail is not None:
                 tail.commit()
             if self.pad is not None:
@@ -635,6 +652,8 @@ class StepPlan:
         """the step of a hipGraph-captured loop (``nic_fused_forward_backward_img_dev``): origins from a device buffer, the step number from
         device memory (added to ``noise_base``), the loss into ``loss_slot``.  Touches no host state and allocates nothing: capture-safe; the
         grid-gradient part of the bucket must be clean (``optim.FusedAdam`` zeroes it in its own launch, NIC_ADAM_ZERO_GRAD)."""
+        if self.timg is None:
+            raise TypeError("the captured step reads its targets from a resident TargetImage")
         d = self.d
         d.noise_mode = int(noise_mode)
         d.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
