@@ -1482,15 +1482,22 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
 
 // =====================================================================================================
 // Fixed-order reduction of the records of fused_q16_kernel.  Output index space, layer by layer:
-// W1 [64][Cin] | b1 [64] | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
+// dW1 (+ db1 on its constant-one column) in RECORD order - the 2 KF 32x32 tiles of the full k-steps, element by element, then the 64 x 16 block of the
+// half k-step - | (W_hidden [64][64] | b_hidden [64]) x NH | W_out [3][64] | b_out [3] | loss.
+// (Round 4: the dW1 part used to walk nn.Linear order and SEARCH the slot of every channel (rho_of_channel: up to KP evaluations of slot_channel per
+// thread) - 66 us for the multi-level layouts, whose runs of consecutive channels are 4 long, against 14 us for the same records read in record order.)
+template <class Q>
+__host__ __device__ constexpr int reduce_q16_w1_outputs() { return QInfo<Q>::NT1 * 1024 + (QInfo<Q>::HALF ? kH * 16 : 0); }
+template <class Q, int NL>
+__host__ __device__ constexpr int reduce_q16_outputs() { return reduce_q16_w1_outputs<Q>() + (NL - 2) * (kH * kH + kH) + 3 * kH + 3 + 1; }
 template <class Q, int NL>
 __global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale, const StepTail tl) {
     if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = LdsQ<Q, NL>;
     using I = QInfo<Q>;
     constexpr int NH = S::NH, KF = I::KF;
-    constexpr int N_W1 = kH * Q::CIN, N_HID = kH * kH + kH;
-    constexpr int N_OUT = N_W1 + kH + NH * N_HID + 3 * kH + 3 + 1;
+    constexpr int N_W1 = reduce_q16_w1_outputs<Q>(), N_HID = kH * kH + kH;
+    constexpr int N_OUT = reduce_q16_outputs<Q, NL>();
     __shared__ float red[NIC_RQ_SLICES][32];
     const int slice = threadIdx.x >> 5;
     const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -1500,26 +1507,32 @@ __global__ void __launch_bounds__(32 * NIC_RQ_SLICES) reduce_q16_kernel(const fl
     auto tile32 = [](int i, int j) { return ((i & 3) + 4 * (i >> 3)) * 64 + j + 32 * ((i >> 2) & 1); };      // element (row i, column j) of a 32x32 accumulator tile
     if (live) {
         int t = gid;
-        if (t < N_W1 + kH) {
-            int o, ch;
-            if (t < N_W1) { o = t / Q::CIN; ch = t - o * Q::CIN; dst = gr.w[0] ? gr.w[0] + t : nullptr; }
-            else { o = t - N_W1; ch = kSlotOne; dst = gr.b[0] ? gr.b[0] + o : nullptr; }        // db1 rode through dW1 on the constant-one column
-            const int r = I::rho_of_channel(ch), po = pos16(o);
+        if (t < N_W1) {
+            int po, r;
             nsrc = 1;
-            if (r < 32 * KF) {
+            if (t < I::NT1 * 1024) {
+                // element e of 32x32 tile `tile` = (row half to, column block tk): register e >> 6 of lane e & 63 is row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column lane & 31
+                const int tile = t >> 10, e = t & 1023, reg = e >> 6, ln = e & 63;
+                po = 32 * (tile / KF) + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+                r = 32 * (tile % KF) + (ln & 31);
                 // phase NH: the tile's owner wave and accumulator slot (LdsQ)
                 int w, slot;
-                const int tile = (po >> 5) * KF + (r >> 5);
                 if (S::ML) { w = tile & 7; slot = S::D1SLOT + (tile >> 3); }
                 else if (I::NT1 <= 4) { w = 4 * (NH & 1) + tile; slot = NH >> 1; }
                 else { w = tile; slot = (w >> 2) == (NH & 1) ? NH >> 1 : S::XSLOT; }
-                off0 = S::REC_W + (w * S::NACC + slot) * 1024 + tile32(po & 31, r & 31);
+                off0 = S::REC_W + (w * S::NACC + slot) * 1024 + e;
             } else {
-                const int m = po & 15;
-                off0 = S::REC_TAIL + (4 * S::TAIL_HALF + (po >> 4)) * 256 + (m & 3) * 64 + 16 * (m >> 2) + (r - 32 * KF);
+                // the half k-step's 16 columns: 16x16 tiles, register v >> 6 of lane v & 63 is row (v >> 6) + 4 ((v >> 4) & 3), column v & 15
+                const int u = t - I::NT1 * 1024, q = u >> 8, v = u & 255;
+                po = 16 * q + 4 * ((v >> 4) & 3) + (v >> 6);
+                r = 32 * KF + (v & 15);
+                off0 = S::REC_TAIL + (4 * S::TAIL_HALF + q) * 256 + v;
             }
+            const int o = hid16(po), ch = r < I::KP ? I::channel_of_rho(r) : kSlotZero;
+            if (ch >= 0) dst = gr.w[0] ? gr.w[0] + o * Q::CIN + ch : nullptr;
+            else if (ch == kSlotOne) dst = gr.b[0] ? gr.b[0] + o : nullptr;                  // db1 rode through dW1 on the constant-one column
         } else {
-            t -= N_W1 + kH;
+            t -= N_W1;
             if (t < NH * N_HID) {
                 const int k = t / N_HID, u = t - k * N_HID;
                 if (u < kH * kH) {
