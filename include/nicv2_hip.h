@@ -141,6 +141,13 @@ typedef struct nic_path_desc {
  * products by 2^-k where it leaves the kernel (exact): k = nic_path_desc.dz_scale_log2, or - 0 - chosen from loss_scale by the MSE entry points.  Default
  * channel counts; takes precedence over NIC_FLAG_BF16 and NIC_FLAG_SPLIT_BF16. */
 #define NIC_FLAG_FP16 128
+/* The `origins` argument of the FUSED entry points (nic_fused_*) points to HOST memory: num_crops x dim int32 values, num_crops <= NIC_ORIGINS_INLINE_MAX,
+ * read during the call and handed to the kernel by value.  The host loop of the reference draws its crop origins on the host
+ * (image_compression.py:26-50): a step then needs no upload (a 5 us copy in front of a 0.1 ms kernel) and the kernel no dependent global load in front
+ * of its gathers.  Not for the captured loop (nic_fused_forward_backward_img_dev reads the origins nic_sampler_step_begin wrote) nor for the
+ * layer-wise entry points (nic_encode*, nic_gather_corners, ..: NIC_E_ARG). */
+#define NIC_FLAG_ORIGINS_HOST 256
+#define NIC_ORIGINS_INLINE_MAX 16
 
 /* ColorDecoder parameters (image_compression.py:54-68): state_dict keys decoder.{0,2,4}.{weight,bias}.  The reference hard-codes 3
  * Linear layers (n_linear = 3, or 0); n_linear = 5 is the "4 x 64" decoder of BASELINE.json's north star - Linear(Cin,H), three

@@ -27,6 +27,8 @@ NIC_FLAG_GRID_BF16 = 16
 NIC_FLAG_GRID_FP16 = 32
 NIC_FLAG_BF16 = 64
 NIC_FLAG_FP16 = 128
+NIC_FLAG_ORIGINS_HOST = 256          # fused entry points: `origins` is host memory (<= NIC_ORIGINS_INLINE_MAX crops), passed to the kernel by value
+NIC_ORIGINS_INLINE_MAX = 16
 NIC_MAX_LINEAR = 5
 
 

@@ -133,6 +133,7 @@ namespace {
 int check_geometry(const nic_path_desc* d, bool training = false) {
     if (d->num_crops < 1) return NIC_E_SHAPE;
     if (!training && d->tail) return NIC_E_ARG;                                  // the optimiser tail: training entry points only
+    if ((d->flags & NIC_FLAG_ORIGINS_HOST) && d->num_crops > NIC_ORIGINS_INLINE_MAX) return NIC_E_ARG;
     if (d->max_workgroups < 0) return NIC_E_ARG;
     if (d->passes < 0 || (!training && d->passes > 1)) return NIC_E_ARG;           // passes: training entry points only
     for (int a = 0; a < d->dim; ++a)
@@ -261,6 +262,10 @@ void fill_encode(FusedParams& p, const nic_path_desc* d, const FusedInfo& fi, co
     p.g1.p = g1; p.g1.nx = d->g1_nodes[0]; p.g1.ny = d->g1_nodes[1]; p.g1.nz = d->dim == 3 ? d->g1_nodes[2] : 1;
     p.g1.plane = (int64_t)p.g1.nx * p.g1.ny * p.g1.nz;
     p.origins = origins;
+    if (d->flags & NIC_FLAG_ORIGINS_HOST) {                 // host values: by value in the kernel arguments (check_geometry bounds num_crops)
+        p.origins = nullptr;
+        for (int i = 0; i < d->num_crops * d->dim && i < NIC_ORIGINS_INLINE_MAX * 3; ++i) p.org_inl[i] = origins[i];
+    }
     const int ez = d->dim == 3 ? d->extent[2] : 1;
     p.d.extent[2] = ez;
     p.n_per_crop = (int64_t)d->extent[0] * d->extent[1] * ez;
@@ -492,6 +497,7 @@ int fused_train(const nic_path_desc* d, const float* g0, const float* g1, const 
     if (f16) set_f16(p, d, target != nullptr || img != nullptr);
     if (p.grid_kind != 0 && !(mlpn || t16 || q16)) return NIC_E_UNSUPPORTED;
     if (step_dev != nullptr && !(t16 || q16)) return NIC_E_UNSUPPORTED;                // the device-side step: the two-waves-per-SIMD kernels
+    if (step_dev != nullptr && (d->flags & NIC_FLAG_ORIGINS_HOST)) return NIC_E_ARG;     // .. reads the origins the device sampler wrote
     p.step_dev = step_dev;
     p.partials = (float*)workspace;
     const int wpw = (t16 || q16) ? 8 : 4;                     // waves per workgroup = work units per workgroup round

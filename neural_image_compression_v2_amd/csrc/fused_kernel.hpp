@@ -90,7 +90,8 @@ struct FusedParams {
     float* g0_grad;
     float* g1_grad;
     MlPair ml[NIC_ML_MAX_LEVELS];      // multi-level layouts only: pair l (pair 0 repeats g0 / g1 / their gradients); pair l's step is 2^(d.log2_step - 2 l)
-    const int32_t* origins;
+    const int32_t* origins;            // device memory - or null: the origins ride in the kernel arguments (NIC_FLAG_ORIGINS_HOST: a step of a host loop
+    int32_t org_inl[NIC_ORIGINS_INLINE_MAX * 3];   // whose origins are host values needs no upload and no dependent global load in front of its gathers)
     const float* W[NIC_MAX_LINEAR];
     const float* b[NIC_MAX_LINEAR];
     int n_linear;
@@ -140,6 +141,9 @@ struct FusedParams {
     // for launches of at most 4 macro-tiles per wave of the chip
     int preadd_y;
 };
+
+// origin component `idx` (= crop * DIM + axis) of the launch
+__device__ __forceinline__ int origin_of(const FusedParams& p, int idx) { return p.origins != nullptr ? p.origins[idx] : p.org_inl[idx]; }
 // the launch's noise source with the device-side step added to its offset (uniform: scalar registers)
 __device__ __forceinline__ NoiseSrc noise_with_step(const NoiseSrc& base, const int64_t* step_dev) {
     NoiseSrc ns = base;
@@ -1076,7 +1080,7 @@ __global__ void __launch_bounds__(256, MODE == MODE_INFER ? 2 : 1) fused_kernel(
             const int lc[3] = {p.pk_nc > 0 ? pk_lc[0] : pl & ((1 << lw) - 1), p.pk_nc > 0 ? pk_lc[1] : pl >> lw, p.pk_nc > 0 ? pk_lc[2] : 0};
 #pragma unroll
             for (int a = 0; a < L::DIM; ++a) {
-                org[a] = p.origins[crop * L::DIM + a];
+                org[a] = origin_of(p, crop * L::DIM + a);
                 blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
         }

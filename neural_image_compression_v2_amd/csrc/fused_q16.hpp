@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(512) NIC_Q16_ATTR fused_q16_kernel(FusedParams
             const int lc[3] = {packed ? pk_lc[0] : n16 & ((1 << lw) - 1), packed ? pk_lc[1] : n16 >> lw, packed ? pk_lc[2] : 0};
 #pragma unroll
             for (int a = 0; a < D; ++a) {
-                org[a] = p.origins[crop * D + a];
+                org[a] = origin_of(p, crop * D + a);
                 blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
 #pragma unroll

@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
             const int lc[2] = {n16 & ((1 << lw) - 1), n16 >> lw};
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                org[a] = p.origins[crop * 2 + a];
+                org[a] = origin_of(p, crop * 2 + a);
                 blk[a] = (org[a] >> p.lm) + boff[a] + lc[a];
             }
 #pragma unroll

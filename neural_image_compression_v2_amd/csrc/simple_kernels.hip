@@ -446,6 +446,7 @@ static int check_desc_common(const nic_path_desc* d) {
     // the element-wise kernels shift: any cell size up to 2^16 samples (the reference's own steps are 1/4 .. 2; the multi-level extension reads pair l at 4^-(l+1))
     if (d->log2_step < -16 || d->log2_step > 8) return NIC_E_ARG;
     if (d->passes < 0 || d->passes > 1) return NIC_E_ARG;             // passes: the fused training entry points only
+    if (d->flags & NIC_FLAG_ORIGINS_HOST) return NIC_E_ARG;           // the layer-wise kernels read their origins from device memory
     return NIC_OK;
 }
 

@@ -606,7 +606,11 @@ class StepPlan:
                     col = [r[a] for r in rows]
                     if min(col) < 0 or max(col) > self.hi[a]:
                         raise IndexError(f"axis {a}: crop origin {min(col)}..{max(col)} outside [0, {self.hi[a]}] (image / grid bounds)")
-                org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
+                if geo.num_crops <= _lib.NIC_ORIGINS_INLINE_MAX and os.environ.get("NIC_NO_HOST_ORIGINS") != "1":
+                    # host values ride in the kernel arguments (NIC_FLAG_ORIGINS_HOST): no upload, no dependent global load in front of the gathers
+                    org = (ctypes.c_int32 * self.n_org)(*[int(v) for r in rows for v in r])
+                else:
+                    org = host.to(torch.int32).reshape(-1).to(dev, non_blocking=True)     # (a pinned staging ring + async copies measured 10 - 100 x slower here)
             slot = self.steps % self.LOSS_SLOTS
             if slot == 0 and self.steps > 0:
                 self.loss_buf = torch.zeros(self.LOSS_SLOTS, dtype=torch.float32, device=self.dev)
@@ -624,21 +628,27 @@ class StepPlan:
                 self.pad.pad()
                 tail = None                  # zero-padded decoders reduce into padded copies: their step stays a launch of its own
             d.tail = tail.struct_ptr if tail is not None else None
+            host_org = not isinstance(org, torch.Tensor)
+            org_p = ctypes.cast(org, ctypes.c_void_p) if host_org else _lib.ptr(org)
+            flags0 = d.flags
+            if host_org:
+                d.flags = flags0 | _lib.NIC_FLAG_ORIGINS_HOST
             if events is not None:           # (start, end) event pair recorded on the launch stream (bench.KernelEvents brackets the fused kernel alone)
                 events[0].record(torch.cuda.current_stream(dev))
             try:
                 if self.timg is not None:
                     _lib.check(self.lib.nic_fused_forward_backward_img(
-                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
+                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), org_p, ctypes.byref(self.m), None, ctypes.byref(self.timg), None,
                         self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
                         "nic_fused_forward_backward_img")
                 else:
                     _lib.check(self.lib.nic_fused_forward_backward(
-                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(org), ctypes.byref(self.m), None, _lib.ptr(self.target), None,
+                        ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), org_p, ctypes.byref(self.m), None, _lib.ptr(self.target), None,
                         self.loss_base + 4 * slot, _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
                         "nic_fused_forward_backward")
             finally:
                 d.tail = None
+                d.flags = flags0
             if events is not None:
                 events[1].record(torch.cuda.current_stream(dev))
             if tail is not None:

@@ -369,3 +369,49 @@ def test_multilevel_step_with_and_without_the_tail(dev):
     for i, (x, y) in enumerate(zip(pa, pb)):
         err = float((x - y).abs().max() / y.abs().max())
         assert err <= 5e-3, (i, err)
+
+
+@pytest.mark.parametrize("kind", ["2d-split", "2d-bf16", "3d-m3-bf16", "3d-m4-split"])
+def test_host_origins_by_value_equal_device_origins(dev, kind):
+    """NIC_FLAG_ORIGINS_HOST (round 4): the host loop's crop origins ride in the kernel arguments instead of a device buffer - same step.  StepPlan.run
+    with a host list (by value) against the same origins as a device tensor (read by the kernel from memory), every kernel family of the training
+    step: loss and decoder gradients bit for bit, grid gradients to atomic order; the layer-wise entry points and more than NIC_ORIGINS_INLINE_MAX crops
+    are refused on the host."""
+    from neural_image_compression_v2_amd import _lib, fused
+    dim, method, kw = {"2d-split": (2, 1, dict(split_bf16=True)), "2d-bf16": (2, 1, dict(bf16=True)), "3d-m3-bf16": (3, 3, dict(bf16=True)),
+                       "3d-m4-split": (3, 4, dict(split_bf16=True))}[kind]
+    masters, _, params, _ = _fit(dev, dim, method, 3, torch.float32, seed=12)
+    extent = (48, 40) if dim == 2 else (16, 12, 8)
+    size = 256 if dim == 2 else 64
+    rs = np.random.RandomState(3)
+    ncrops = 5
+    org = [[int(rs.randint(0, size - e + 1)) for e in extent] for _ in range(ncrops)]
+    img = torch.rand(3, *([size] * dim), generator=torch.Generator().manual_seed(1)).to(dev)
+    geo = fused.PathGeometry(dim=dim, method=method, step_number=0.25, mip_level=0, extent=extent, num_crops=ncrops, use_tri_pe=method != 4, **kw)
+    outs = {}
+    for mode in ("host", "device"):
+        plan = fused.StepPlan(geo, masters[0], masters[1], params, fused.TargetImage(img))
+        coord = org if mode == "host" else torch.tensor(org, dtype=torch.int32, device=dev)
+        o = plan.run(coord, _lib.NIC_NOISE_KERNEL, 9, 4)
+        torch.cuda.synchronize()
+        outs[mode] = (float(o.loss), [t.clone() for t in o.grad_mlp], o.grad_g0.clone(), o.grad_g1.clone())
+    a, b = outs["host"], outs["device"]
+    assert a[0] == b[0]
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
+    for x, y in ((a[2], b[2]), (a[3], b[3])):
+        assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max())
+    assert float(a[2].abs().max()) > 0
+    # refusals
+    d = geo.to_desc(masters[0].detach(), masters[1].detach())
+    d.flags |= _lib.NIC_FLAG_ORIGINS_HOST
+    harr = (ctypes.c_int32 * (ncrops * dim))(*[v for r in org for v in r])
+    out = torch.empty(ncrops * int(np.prod(extent)), geo.cin, device=dev)
+    rc = _lib.load().nic_encode(ctypes.byref(d), _lib.ptr(masters[0].detach()), _lib.ptr(masters[1].detach()), ctypes.cast(harr, ctypes.c_void_p), _lib.ptr(out), _lib.stream_ptr(dev))
+    assert rc < 0
+    d.num_crops = _lib.NIC_ORIGINS_INLINE_MAX + 1
+    y = torch.empty(8, 3, device=dev)
+    m = fused._mlp_struct([p.detach() for p in params])
+    rc = _lib.load().nic_fused_forward(ctypes.byref(d), _lib.ptr(masters[0].detach()), _lib.ptr(masters[1].detach()), ctypes.cast(harr, ctypes.c_void_p), ctypes.byref(m), None,
+                                       _lib.ptr(y), _lib.stream_ptr(dev))
+    assert rc < 0
