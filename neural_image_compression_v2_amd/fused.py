@@ -658,7 +658,7 @@ class StepPlan:
         return StepOutput(self.loss_buf[slot], None, self.gg0, self.gg1, self.gm, self.flat)
 
     def launch_dev(self, origins_dev: torch.Tensor, step_dev_ptr: int, loss_slot: torch.Tensor, ws: torch.Tensor, noise_mode: int, noise_seed: int,
-                   noise_base: int = 0) -> None:
+                   noise_base: int = 0, tail_struct=None) -> None:
         """the step of a hipGraph-captured loop (``nic_fused_forward_backward_img_dev``): origins from a device buffer, the step number from
         device memory (added to ``noise_base``), the loss into ``loss_slot``.  Touches no host state and allocates nothing: capture-safe; the
         grid-gradient part of the bucket must be clean (``optim.FusedAdam`` zeroes it in its own launch, NIC_ADAM_ZERO_GRAD)."""
@@ -670,10 +670,15 @@ class StepPlan:
         d.noise_offset = int(noise_base) & 0xFFFFFFFFFFFFFFFF
         if self.pad is not None:
             self.pad.pad()
-        _lib.check(self.lib.nic_fused_forward_backward_img_dev(
-            ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(origins_dev), ctypes.byref(self.m), ctypes.byref(self.timg),
-            _lib.ptr(loss_slot), _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), ctypes.c_void_p(step_dev_ptr), _lib.ptr(ws), ws.numel(),
-            _lib.stream_ptr(self.dev)), "nic_fused_forward_backward_img_dev")
+        # tail_struct: a NicStepTail with the device schedule (optim.DevAdam.tail_struct) - the optimiser rides on the reduction launch of the captured step
+        d.tail = ctypes.addressof(tail_struct) if (tail_struct is not None and self.pad is None) else None
+        try:
+            _lib.check(self.lib.nic_fused_forward_backward_img_dev(
+                ctypes.byref(d), _lib.ptr(self.g0), _lib.ptr(self.g1), _lib.ptr(origins_dev), ctypes.byref(self.m), ctypes.byref(self.timg),
+                _lib.ptr(loss_slot), _lib.ptr(self.gg0), _lib.ptr(self.gg1), ctypes.byref(self.gs), ctypes.c_void_p(step_dev_ptr), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(self.dev)), "nic_fused_forward_backward_img_dev")
+        finally:
+            d.tail = None
         if self.pad is not None:
             self.pad.unpad(self.gm)
 

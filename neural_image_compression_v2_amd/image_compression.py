@@ -429,11 +429,15 @@ class ImageCompression:
             org = torch.zeros(c.NUM_CROPS * D, dtype=torch.int32, device=dev)
             seed = self._sampler.seed
 
+            # the optimiser rides on the reduction launch of the fused step (nic_path_desc.tail with the device schedule): sampler + 2 launches per step
+            tail_s = adam.tail_struct(2) if (plan.pad is None and os.environ.get("NIC_NO_TAIL") != "1") else None
+
             def one_step():
                 _lib.check(lib.nic_sampler_step_begin(seed, _lib.ptr(counters), c.NUM_CROPS, D, rng, _lib.ptr(org), _lib.ptr(loss_slot), _lib.ptr(hist),
                                                       hist.numel(), _lib.stream_ptr(dev)), "nic_sampler_step_begin")
-                plan.launch_dev(org, step_ptr, loss_slot, ws, _lib.NIC_NOISE_KERNEL, noise_seed)
-                adam.launch(step_ptr)
+                plan.launch_dev(org, step_ptr, loss_slot, ws, _lib.NIC_NOISE_KERNEL, noise_seed, tail_struct=tail_s)
+                if tail_s is None:
+                    adam.launch(step_ptr)
 
             with torch.cuda.device(dev):
                 one_step()                                              # the first step uncaptured: argument errors surface here, not inside a capture
@@ -459,7 +463,7 @@ class ImageCompression:
                     one_step()
                     done += 1
                 hist[e_end - 1:e_end].copy_(loss_slot)                  # the last step's loss has no successor to file it
-            self._graph_keep = (counters, hist, loss_slot, ws, org, adam)   # alive until the stream has drained
+            self._graph_keep = (counters, hist, loss_slot, ws, org, adam, tail_s)   # alive until the stream has drained
             adam.commit(n)
             self.scheduler.advance(n)
             plan.clean = True

@@ -310,6 +310,16 @@ class DevAdam:
     def __init__(self, opt, arr, count, key, sched, params, zeroed, device):
         self.opt, self.arr, self.count, self.key, self.sched, self.params, self.zeroed, self.device = opt, arr, count, key, sched, params, zeroed, device
 
+    def tail_struct(self, n_stream: int) -> "_lib.NicStepTail":
+        """this table as the tail of the captured fused step (nic_path_desc.tail with the device schedule: nic_fused_forward_backward_img_dev reads
+        row *step_dev): the first ``n_stream`` entries are streamed (the grids), the rest are the decoder's tensors"""
+        t = _lib.NicStepTail()
+        t.tensors = ctypes.cast(self.arr, ctypes.c_void_p).value
+        t.count, t.n_stream = self.count, int(n_stream)
+        t.beta1, t.beta2, t.eps = self.key
+        t.sched, t.sched_rows = self.sched.data_ptr(), int(self.sched.shape[0])
+        return t
+
     def launch(self, step_dev_ptr: int) -> None:
         b1, b2, eps = self.key
         _lib.check(_lib.load().nic_adam_multi_dev(self.arr, self.count, b1, b2, eps, _lib.ptr(self.sched), int(self.sched.shape[0]),
