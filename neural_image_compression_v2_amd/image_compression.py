@@ -94,6 +94,21 @@ class ImageCompression:
         self.images: List[torch.Tensor] = []
         self.loss_history: List[torch.Tensor] = []
         self.step_count = 0
+        if c.TF_PRINT_LOG and os.environ.get("NIC_QUIET") != "1":
+            import sys
+            print(f"[nicv2] product arithmetic of the fused steps: {self.arithmetic}", file=sys.stderr, flush=True)
+
+    @property
+    def arithmetic(self) -> str:
+        """the resolved arithmetic of the fused training steps and decodes of this configuration (Settings.TF_PLAIN_BF16 / TF_PLAIN_FP16 / TF_SPLIT_BF16):
+        what a fit's numbers have to be read against - fp32-equivalent by default, the plain 16-bit modes are opt-ins"""
+        c = self.cfg
+        if c.plain_bf16:
+            return ("plain fp16 operands (NIC_FLAG_FP16), fp32 accumulate: outputs ~2e-5, gradients ~1e-3 from fp32" if getattr(c, "TF_PLAIN_FP16", False)
+                    else "plain bf16 operands (NIC_FLAG_BF16), fp32 accumulate: outputs ~2e-4, gradients ~5e-3 from fp32")
+        if c.TF_SPLIT_BF16:
+            return "split-bf16 operands (hi + lo pairs, NIC_FLAG_SPLIT_BF16), fp32 accumulate: fp32-equivalent (5e-6)"
+        return "fp32 matrix products"
 
     # ------------------------------------------------------------------ geometry helpers
     def _method(self) -> int:
