@@ -18,9 +18,10 @@ static int launch_q16_nl(int mode, const FusedParams& p, int grid, hipStream_t s
 template <class Q, int NL>
 static int reduce_q16_nl(const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
     constexpr int n_out = reduce_q16_outputs<Q, NL>();
-    static_assert(32 * NIC_RQ_SLICES == 256, "the tail's streaming blocks are 256 threads wide (nic_adam.hpp)");
-    const TailLaunch t = tail_for((n_out + 31) / 32);
-    hipLaunchKernelGGL((reduce_q16_kernel<Q, NL>), dim3(t.blocks), dim3(32 * NIC_RQ_SLICES), 0, s, partials, n_rec, g, loss, loss_scale, t.tl);
+    static_assert(256 % NIC_RQ_SLICES == 0, "256 threads per block (the tail's streaming blocks too: nic_adam.hpp)");
+    constexpr int outs = 256 / NIC_RQ_SLICES;
+    const TailLaunch t = tail_for((n_out + outs - 1) / outs);
+    hipLaunchKernelGGL((reduce_q16_kernel<Q, NL>), dim3(t.blocks), dim3(256), 0, s, partials, n_rec, g, loss, loss_scale, t.tl);
     return (int)hipGetLastError();
 }
 

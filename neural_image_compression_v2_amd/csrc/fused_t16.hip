@@ -20,7 +20,8 @@ int launch_train16(int layout, int mode, const FusedParams& p, int grid, hipStre
 }
 
 int launch_reduce16(int layout, const float* partials, int n_rec, nic_mlp_grads g, float* loss, float loss_scale, hipStream_t s) {
-    const TailLaunch t = tail_for((kR16_SRC + 31) / 32);
+    constexpr int outs = 256 / NIC_R16_SLICES;
+    const TailLaunch t = tail_for((kR16_SRC + outs - 1) / outs);
     const dim3 grid(t.blocks), block(256);
     if (layout == 1) hipLaunchKernelGGL((reduce16_kernel<Layout<1>>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale, t.tl);
     else hipLaunchKernelGGL((reduce16_kernel<Layout<2>>), grid, block, 0, s, partials, n_rec, g, loss, loss_scale, t.tl);

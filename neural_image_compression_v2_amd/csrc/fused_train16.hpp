@@ -986,13 +986,17 @@ __global__ void __launch_bounds__(NIC_T16_LB) fused_train16_kernel(FusedParams p
 //   [8192, 9216)   dW1 columns 64..79: row group po >> 4, register r, lane - two partial sums 4 x 256 apart
 //   [9216, 9536)   per-wave tails: db2 [64] | dW3 [3][64] | db3 [3] | loss | unused - 8 partial sums 320 apart
 constexpr int kR16_SRC = 4096 + 4096 + 1024 + 320;
+#ifndef NIC_R16_SLICES
+#define NIC_R16_SLICES 8       // see NIC_RQ_SLICES (fused_q16.hpp)
+#endif
 template <class L>
 __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, int n_rec, nic_mlp_grads gr, float* loss, float loss_scale, const StepTail tl) {
     if (tail_block(tl)) return;                                   // a streaming block of the optimiser tail (nic_adam.hpp)
     using S = Lds16;
-    __shared__ float red[8][32];
-    const int slice = threadIdx.x >> 5;
-    const int gid = blockIdx.x * 32 + (threadIdx.x & 31);
+    constexpr int SL = NIC_R16_SLICES, OUTS = 256 / SL;           // record slices summed in parallel x outputs per block
+    __shared__ float red[SL][OUTS];
+    const int slice = threadIdx.x / OUTS, oi = threadIdx.x % OUTS;
+    const int gid = blockIdx.x * OUTS + oi;
     const bool live = gid < kR16_SRC;
     int nsrc = 0, off0 = 0, stride = 0;
     float* dst = nullptr;
@@ -1030,7 +1034,7 @@ __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, in
         }
     }
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // fixed summation tree: bit-stable for a given grid size
-    const int per = (n_rec + 7) >> 3;
+    const int per = (n_rec + SL - 1) / SL;
     const int w_lo = slice * per, w_hi = (w_lo + per < n_rec) ? w_lo + per : n_rec;
     if (live && dst != nullptr) {
         for (int k = 0; k < nsrc; ++k) {
@@ -1043,12 +1047,12 @@ __global__ void __launch_bounds__(256) reduce16_kernel(const float* partials, in
             for (; w < w_hi; ++w) part[0] += src[(int64_t)w * S::REC];
         }
     }
-    red[slice][threadIdx.x & 31] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    red[slice][oi] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     __syncthreads();
     if (slice != 0 || !live || dst == nullptr) return;
-    float acc = red[0][threadIdx.x];
+    float acc = red[0][oi];
 #pragma unroll
-    for (int sl = 1; sl < 8; ++sl) acc += red[sl][threadIdx.x];
+    for (int sl = 1; sl < SL; ++sl) acc += red[sl][oi];
     if (is_loss) *dst = acc * loss_scale;
     else tail_store(tl, dst, acc);
 }
