@@ -415,3 +415,31 @@ def test_host_origins_by_value_equal_device_origins(dev, kind):
     rc = _lib.load().nic_fused_forward(ctypes.byref(d), _lib.ptr(masters[0].detach()), _lib.ptr(masters[1].detach()), ctypes.cast(harr, ctypes.c_void_p), ctypes.byref(m), None,
                                        _lib.ptr(y), _lib.stream_ptr(dev))
     assert rc < 0
+
+
+def test_bench_line_keeps_the_driver_contract(dev):
+    """``python bench.py --steps K --warmup W`` (what the driver runs): exactly ONE line on stdout, JSON, with the contract's keys, the `roofline` and
+    `cpu_baseline` objects, a kernel time that brackets the fused kernel alone (<= the step), and a step that is two launches' worth of time"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--stat-launches", "0"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "issue", "hbm_cell_granular"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.5 * d["ms_per_step"] < rf["kernel_ms"] <= d["ms_per_step"]
+    assert abs(d["value"] - 3840 * 2160 / d["ms_per_step"] / 1e3) <= 0.01 * d["value"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
