@@ -443,3 +443,24 @@ def test_bench_line_keeps_the_driver_contract(dev):
     assert abs(d["value"] - 3840 * 2160 / d["ms_per_step"] / 1e3) <= 0.01 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(dev):
+    """the N > 1 path of bench.py end to end on real kernels: two ranks on this one GPU over gloo (NIC_DIST_BACKEND=gloo: the rehearsal mode; the numbers mean
+    nothing) - strong scaling, stripe-sharded grids with the interior-row optimiser inside the exchange, and the replicated leg beside it in the same line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--stat-launches", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2
+    legs = d["shard_legs"]
+    assert legs["stripes"]["value"] == d["value"] and legs["replicated"]["all_reduce_bytes_per_step"] > 30e6
+    assert "stripes" in d["config"]["parallelism"] and np.isfinite(d["config"]["final_loss"]) and d["config"]["final_loss"] > 0
+    assert d["config"]["psnr_db_after_these_steps"] > 5.0                       # the assembled stripes decode to an image
